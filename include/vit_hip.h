@@ -1,0 +1,130 @@
+/*
+ * vit_hip.h -- C ABI of the MI355X (gfx950) Viterbi hot path: update() + chainback().
+ *
+ * This is the drop-in boundary.  The reference (williamyang98/ViterbiDecoderCpp) has no FFI layer: its hot path sits
+ * behind a C++ template concept (static update()) plus a state object with public fields.  The C++ host layer in
+ * include/viterbi_hip/ keeps that surface and forwards to the entry points below; bindings in any other language bind
+ * these symbols directly.  Plain pointers and sizes only: no HIP, torch or C++ types.
+ *
+ * Reference interface each entry point replaces (paths relative to the reference tree):
+ *   vit_hip_create            ViterbiDecoder_Core ctor            include/viterbi/viterbi_decoder_core.h:170-177
+ *                             (+ ViterbiBranchTable::data()       include/viterbi/viterbi_branch_table.h:64-66,
+ *                                ViterbiDecoder_Config            include/viterbi/viterbi_decoder_config.h:11-18)
+ *   vit_hip_update_batch      reset() + Decoder::update<sum_t>()  viterbi_decoder_core.h:202-211, viterbi_decoder_scalar.h:29-55
+ *   vit_hip_chainback_batch   chainback()                         viterbi_decoder_core.h:214-236
+ *   vit_hip_decode_batch      the call pattern reset->update->chainback of examples/run_simple.cpp:76-80
+ *   vit_hip_update_host       update() on a host-resident Core (streaming, N = R allowed:
+ *                                                                 examples/helpers/puncture_code_helpers.h:51)
+ *   vit_hip_chainback_host    chainback() on host-resident decision rows
+ *   vit_hip_export_decisions  ViterbiDecisionBits rows            viterbi_decoder_core.h:49-83 (m_decisions[t][w])
+ *
+ * Semantics are those of the reference SCALAR strategy (strict '>' decision, wrapping error_t arithmetic,
+ * renormalise only when new_metric[0] >= threshold): SURVEY.md section 8(a').  All results are bit-exact.
+ *
+ * Conventions
+ *   - every function returns VIT_HIP_OK (0) or a negative VIT_HIP_ERR_*; no exception crosses the ABI;
+ *     vit_hip_last_error() returns a thread-local description of the last failure.
+ *   - pointers named d_* are DEVICE pointers on the handle's device; others are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Batch calls only enqueue work: no
+ *     allocation, no synchronisation, safe to capture into a hipGraph.
+ *   - N = 2^(K-1) states, H = N/2, W = max(N/64, 1) 64-bit decision words per step, S = L + K-1 steps per frame.
+ */
+#ifndef VIT_HIP_H
+#define VIT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_HIP_OK 0
+#define VIT_HIP_ERR_INVALID_ARG (-1)
+#define VIT_HIP_ERR_UNSUPPORTED (-2)
+#define VIT_HIP_ERR_RUNTIME (-3)     /* a HIP runtime call failed              */
+#define VIT_HIP_ERR_NO_DEVICE (-4)   /* no usable GPU: the product path never falls back to the CPU */
+#define VIT_HIP_ERR_WORKSPACE (-5)   /* workspace too small / misaligned       */
+
+/* kernel plans (vit_hip_set_plan): which device implementation serves update()/chainback() */
+#define VIT_HIP_PLAN_AUTO 0
+#define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
+#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, 4 lanes per frame pair (K = 7, 9 codes)              */
+
+typedef struct vit_hip_decoder* vit_hip_handle;
+typedef void* vit_hip_stream_t;
+
+typedef struct vit_hip_info {
+    int32_t K, R, soft_bytes, error_bytes;
+    int32_t num_states;      /* N */
+    int32_t decision_words;  /* W */
+    int32_t device;
+    int32_t plan;            /* resolved plan (VIT_HIP_PLAN_LDS / _REG) */
+    int32_t soft_decision_high, soft_decision_low; /* recovered from the branch table */
+    uint32_t polynomials[16];                      /* recovered G[i] (bit 0 and bit K-1 forced to 1), 0 if not linear */
+    int32_t table_is_linear;
+} vit_hip_info;
+
+const char* vit_hip_last_error(void);
+int vit_hip_device_count(void);
+
+/* branch_table: host, [R][H] soft_t exactly as ViterbiBranchTable::data() lays it out (rows contiguous, no padding).
+ * config: host, 4 x error_t in the order of ViterbiDecoder_Config (max_error, initial_start_error,
+ * initial_non_start_error, renormalisation_threshold).  (soft_bytes, error_bytes) must be (2,2) or (1,1).
+ * The table must be two-valued (high/low); it is copied, the caller's table need not outlive the handle. */
+int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+                   int device, vit_hip_handle* out);
+int vit_hip_destroy(vit_hip_handle h);
+int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info);
+int vit_hip_set_plan(vit_hip_handle h, int plan);
+
+/* Opaque blob carrying everything vit_hip_create needs (header + table + config): the payload broadcast to the other
+ * ranks of a node (RCCL over xGMI via torch.distributed) so that every GPU builds an identical decoder. */
+size_t vit_hip_blob_bytes(int K, int R, int soft_bytes, int error_bytes);
+int vit_hip_pack_blob(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+                      void* blob, size_t blob_bytes);
+int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vit_hip_handle* out);
+
+/* ---- batched, device-resident (the throughput route) --------------------------------------------------------- */
+
+/* bytes of decision workspace needed for `frames` frames of L info bits (layout is plan-specific and opaque). */
+size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L);
+
+/* reset(start_state) + update() over n_steps trellis steps (n_steps <= L + K-1) for every frame.
+ *   d_symbols       [frames][n_steps][R] soft_t, frame-major, step-major, polynomial-minor
+ *   d_workspace     >= vit_hip_workspace_bytes(h, frames, L), 256-byte aligned; receives the decision history
+ *   d_final_metrics [frames][N] error_t or NULL  (Core::m_metrics "old" buffer after the last swap)
+ *   d_renorm_sum    [frames] uint64 or NULL      (update()'s return value)
+ *   d_start_state   [frames] uint32 or NULL (=> 0) */
+int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t L,
+                         void* d_workspace, size_t workspace_bytes, void* d_final_metrics, uint64_t* d_renorm_sum,
+                         const uint32_t* d_start_state, vit_hip_stream_t stream);
+
+/* chainback(bytes_out, L, end_state) for every frame from the workspace a full update (n_steps = L+K-1) filled.
+ *   d_bytes_out [frames][ceil(L/8)] ; d_end_state [frames] uint32 or NULL (=> 0) */
+int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, vit_hip_stream_t stream);
+
+/* update over S = L+K-1 steps from state 0, then chainback: both phases enqueued on `stream`. */
+int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t L, void* d_workspace,
+                         size_t workspace_bytes, uint8_t* d_bytes_out, void* d_final_metrics, uint64_t* d_renorm_sum,
+                         const uint32_t* d_end_state, vit_hip_stream_t stream);
+
+/* decision history in the reference's layout: d_decisions [frames][n_steps][W] uint64, bit s%64 of word s/64 of row t
+ * = decision for next-state s at step t. */
+int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t frames, size_t n_steps, size_t L,
+                             uint64_t* d_decisions, vit_hip_stream_t stream);
+
+/* ---- host-pointer compatibility route (one decoder object, streaming) ------------------------------------------ */
+
+/* update() on a host-resident decoder state: metrics_inout [N] error_t ("old" metrics), symbols n_steps*R soft_t,
+ * decisions_out [n_steps][W] (rows for THIS call), *renorm_sum_out = update()'s return value.  Synchronous. */
+int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps,
+                        uint64_t* decisions_out, uint64_t* renorm_sum_out);
+
+/* chainback() on host-resident rows: decisions [L+K-1][W].  Synchronous. */
+int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L, size_t end_state, uint8_t* bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_HIP_H */

@@ -1,0 +1,78 @@
+"""Shared helpers for the parity tests: build decoders for stock codes and compare against the oracle."""
+import numpy as np
+
+from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config,
+                                   get_decoding_config, synth)
+from oracle import pyoracle
+
+DECODE_TYPES = ["SOFT16", "SOFT8", "HARD8"]
+_DT_ID = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}
+
+
+def oracle_cfg(decode_type, R):
+    return pyoracle.stock_config(_DT_ID[decode_type], R)
+
+
+def make_table_config(code, decode_type):
+    pc = get_decoding_config(decode_type, code.R)
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    config = ViterbiDecoder_Config.from_decoder_config(pc)
+    return pc, table, config
+
+
+def default_ebn0(code, decode_type):
+    # a point where errors, ties and renormalisation all occur
+    base = {"SOFT16": 2.0, "SOFT8": 3.0, "HARD8": 4.0}[decode_type]
+    return base - (6.0 if code.K == 15 else 0.0)
+
+
+def oracle_frames(oracle, code, decode_type, sym, L, n_steps=None, start_state=None, end_state=None):
+    """decode every frame of sym [F][n_steps][R] with the oracle; returns dict of stacked arrays."""
+    ocfg = oracle_cfg(decode_type, code.R)
+    F = sym.shape[0]
+    outs = []
+    for f in range(F):
+        ss = 0 if start_state is None else int(start_state[f])
+        es = 0 if end_state is None else int(end_state[f])
+        outs.append(oracle.decode(code.K, code.R, code.G, ocfg, sym[f], L, start_state=ss, end_state=es))
+    res = dict(decisions=np.stack([o["decisions"] for o in outs]),
+               metrics=np.stack([o["metrics"] for o in outs]),
+               renorm_sum=np.asarray([o["renorm_sum"] for o in outs], dtype=np.uint64))
+    if outs[0]["bytes"] is not None:
+        res["bytes"] = np.stack([o["bytes"] for o in outs])
+    return res
+
+
+def gpu_metrics_to_u32(met, error_bytes):
+    a = met.cpu().numpy()
+    if error_bytes == 2:
+        a = a.view(np.uint16)
+    return a.astype(np.uint32)
+
+
+def check_batch_against_oracle(oracle, code, decode_type, F, L, ebn0, seed, plan=None, sym=None, n_steps=None,
+                               start_state=None, end_state=None):
+    import torch
+
+    pc, table, config = make_table_config(code, decode_type)
+    if sym is None:
+        _, sym = synth.make_frames_numpy(code, pc, F, L, ebn0, seed=seed)
+    S = L + code.K - 1
+    n_steps = S if n_steps is None else n_steps
+    sym = np.ascontiguousarray(sym[:, :n_steps])
+    dec = BatchDecoder(table, config, device=0) if plan is None else BatchDecoder(table, config, device=0, plan=plan)
+    d_sym = torch.from_numpy(sym).cuda()
+    met, rs = dec.update(d_sym, L, n_steps=n_steps, start_state=start_state)
+    want = oracle_frames(oracle, code, decode_type, sym, L, n_steps, start_state, end_state)
+    got_dec = dec.export_decisions(F, L, n_steps).cpu().numpy().view(np.uint64)
+    assert got_dec.shape == want["decisions"].shape
+    bad = np.argwhere(got_dec != want["decisions"])
+    assert bad.size == 0, f"decision words differ first at (frame, step, word) = {bad[0]} of {len(bad)}"
+    assert np.array_equal(gpu_metrics_to_u32(met, pc.error_bytes), want["metrics"]), "final metrics differ"
+    assert np.array_equal(rs.cpu().numpy().astype(np.uint64), want["renorm_sum"]), "renormalisation sums differ"
+    if n_steps == S:
+        out = dec.chainback(F, L, end_state=end_state).cpu().numpy()
+        bad = np.argwhere(out != want["bytes"])
+        assert bad.size == 0, f"chainback bytes differ first at (frame, byte) = {bad[0]} of {len(bad)}"
+    torch.cuda.synchronize()
+    return dec

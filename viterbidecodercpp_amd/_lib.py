@@ -1,0 +1,76 @@
+"""ctypes binding of libvit_hip.so -- the C ABI declared in include/vit_hip.h.
+
+The HIP library is the product: there is no Python or CPU fallback.  `load()` raises if the shared object is missing
+(run `python -c "import __graft_entry__ as g; g.build()"` or `make -C viterbidecodercpp_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvit_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NO_DEVICE, ERR_WORKSPACE = -1, -2, -3, -4, -5
+PLAN_AUTO, PLAN_LDS, PLAN_REG = 0, 1, 2
+PLAN_NAMES = {PLAN_LDS: "lds", PLAN_REG: "reg"}
+
+# every symbol include/vit_hip.h declares
+EXPORTS = [
+    "vit_hip_last_error", "vit_hip_device_count", "vit_hip_create", "vit_hip_destroy", "vit_hip_get_info",
+    "vit_hip_set_plan", "vit_hip_blob_bytes", "vit_hip_pack_blob", "vit_hip_create_from_blob",
+    "vit_hip_workspace_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
+    "vit_hip_export_decisions", "vit_hip_update_host", "vit_hip_chainback_host",
+]
+
+
+class VitHipInfo(C.Structure):
+    _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("soft_bytes", C.c_int32), ("error_bytes", C.c_int32),
+                ("num_states", C.c_int32), ("decision_words", C.c_int32), ("device", C.c_int32), ("plan", C.c_int32),
+                ("soft_decision_high", C.c_int32), ("soft_decision_low", C.c_int32), ("polynomials", C.c_uint32 * 16),
+                ("table_is_linear", C.c_int32)]
+
+
+class VitHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vit_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    L.vit_hip_last_error.restype = C.c_char_p
+    L.vit_hip_device_count.restype = i32
+    L.vit_hip_create.argtypes = [i32, i32, i32, i32, vp, vp, i32, C.POINTER(vp)]
+    L.vit_hip_destroy.argtypes = [vp]
+    L.vit_hip_get_info.argtypes = [vp, C.POINTER(VitHipInfo)]
+    L.vit_hip_set_plan.argtypes = [vp, i32]
+    L.vit_hip_blob_bytes.restype = sz
+    L.vit_hip_blob_bytes.argtypes = [i32, i32, i32, i32]
+    L.vit_hip_pack_blob.argtypes = [i32, i32, i32, i32, vp, vp, vp, sz]
+    L.vit_hip_create_from_blob.argtypes = [vp, sz, i32, C.POINTER(vp)]
+    L.vit_hip_workspace_bytes.restype = sz
+    L.vit_hip_workspace_bytes.argtypes = [vp, sz, sz]
+    L.vit_hip_update_batch.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, vp, vp, vp]
+    L.vit_hip_chainback_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.vit_hip_decode_batch.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.vit_hip_export_decisions.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
+    L.vit_hip_chainback_host.argtypes = [vp, vp, sz, sz, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise VitHipError(rc, load().vit_hip_last_error().decode(errors="replace"))

@@ -1,0 +1,470 @@
+// vit_hip.hip -- C ABI (include/vit_hip.h) over the gfx950 kernels.  Host-side logic only: argument checking, plan
+// selection, workspace layout, launches.  There is no CPU decode path in this library: without a usable GPU every entry
+// point fails with VIT_HIP_ERR_NO_DEVICE / VIT_HIP_ERR_RUNTIME.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vit_hip.h"
+#include "kernels_lds.hpp"
+#include "kernels_reg.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define VIT_HIP_CHECK(expr)                                                                             \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(VIT_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+constexpr uint32_t BLOB_MAGIC = 0x56495442u;  // "VITB"
+
+struct BlobHeader {
+    uint32_t magic;
+    int32_t K, R, soft_bytes, error_bytes;
+};
+
+}  // namespace
+
+struct vit_hip_decoder {
+    int K = 0, R = 0, soft_bytes = 0, error_bytes = 0, device = 0;
+    int N = 0, H = 0, W = 0, shift = 0;
+    int plan = VIT_HIP_PLAN_LDS;
+    int high = 0, low = 0;
+    bool linear = false;
+    uint32_t G[16] = {0};
+    uint32_t cfg_raw[4] = {0, 0, 0, 0};
+    vit::DevConfig cfg{};
+    std::vector<uint16_t> pattern;  // [H] host copy
+    uint16_t* d_pattern = nullptr;
+    vit::RegCode reg_code{};        // PLAN_REG description (valid when reg_ok)
+    bool reg_ok = false;
+    // host-route scratch
+    hipStream_t stream = nullptr;
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int lds_waves(int N) {
+    if (N <= 256) return 1;
+    int w = N / 256;
+    return w > 16 ? 16 : w;
+}
+
+size_t lds_smem_bytes(int N, int waves) {
+    const int H = N / 2;
+    return (size_t)(2 * N + (H > 0 ? H : 1) + waves) * sizeof(uint16_t);
+}
+
+template <int R, int SHIFT>
+int launch_lds_update_t(const vit::LdsUpdateArgs& a, size_t frames, int N, hipStream_t st) {
+    const int waves = lds_waves(N);
+    const size_t smem = lds_smem_bytes(N, waves);
+    auto kern = vit::lds_update_kernel<R, SHIFT>;
+    if (smem > 64 * 1024) {
+        VIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)smem));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)frames), dim3(64 * waves), smem, st, a);
+    VIT_HIP_CHECK(hipGetLastError());
+    return VIT_HIP_OK;
+}
+
+template <int SHIFT>
+int launch_lds_update_r(int R, const vit::LdsUpdateArgs& a, size_t frames, int N, hipStream_t st) {
+    switch (R) {
+        case 1: return launch_lds_update_t<1, SHIFT>(a, frames, N, st);
+        case 2: return launch_lds_update_t<2, SHIFT>(a, frames, N, st);
+        case 3: return launch_lds_update_t<3, SHIFT>(a, frames, N, st);
+        case 4: return launch_lds_update_t<4, SHIFT>(a, frames, N, st);
+        case 5: return launch_lds_update_t<5, SHIFT>(a, frames, N, st);
+        case 6: return launch_lds_update_t<6, SHIFT>(a, frames, N, st);
+        case 7: return launch_lds_update_t<7, SHIFT>(a, frames, N, st);
+        case 8: return launch_lds_update_t<8, SHIFT>(a, frames, N, st);
+        default: return fail(VIT_HIP_ERR_UNSUPPORTED, "code rate R must be 1..8");
+    }
+}
+
+// decisions in the reference layout [F][rows][W]; rows = L + K-1
+int lds_update(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t rows, uint32_t row0,
+               uint64_t* d_decisions, void* d_metrics, bool reset, uint64_t* d_renorm, const uint32_t* d_start,
+               hipStream_t st) {
+    if (frames == 0 || n_steps == 0) return VIT_HIP_OK;
+    vit::LdsUpdateArgs a{};
+    a.symbols = (const uint8_t*)d_symbols;
+    a.sym_frame_stride_bytes = n_steps * (size_t)h->R * (size_t)h->soft_bytes;
+    a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
+    a.decisions = d_decisions;
+    a.dec_frame_stride_words = rows * (size_t)h->W;
+    a.dec_row0 = row0;
+    a.metrics_io = d_metrics;
+    a.renorm_sum = d_renorm;
+    a.start_state = d_start;
+    a.pattern = h->d_pattern;
+    a.K = h->K;
+    a.n_steps = (int)n_steps;
+    a.reset = reset ? 1 : 0;
+    a.cfg = h->cfg;
+    return h->shift ? launch_lds_update_r<8>(h->R, a, frames, h->N, st) : launch_lds_update_r<0>(h->R, a, frames, h->N, st);
+}
+
+int lds_chainback(vit_hip_handle h, const uint64_t* d_decisions, size_t frames, size_t L, uint8_t* d_out,
+                  const uint32_t* d_end, hipStream_t st) {
+    if (frames == 0 || L == 0) return VIT_HIP_OK;
+    vit::LdsChainbackArgs a{};
+    a.decisions = d_decisions;
+    a.dec_frame_stride_words = (L + (size_t)h->K - 1) * (size_t)h->W;
+    a.out = d_out;
+    a.end_state = d_end;
+    a.frames = frames;
+    a.L = L;
+    a.K = h->K;
+    const int block = 64;
+    hipLaunchKernelGGL(vit::lds_chainback_kernel, dim3((unsigned)((frames + block - 1) / block)), dim3(block), 0, st, a);
+    VIT_HIP_CHECK(hipGetLastError());
+    return VIT_HIP_OK;
+}
+
+int ensure_scratch(vit_hip_handle h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return VIT_HIP_OK;
+    if (h->d_scratch) VIT_HIP_CHECK(hipFree(h->d_scratch));
+    h->d_scratch = nullptr;
+    h->scratch_bytes = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    VIT_HIP_CHECK(hipMalloc(&h->d_scratch, want));
+    h->scratch_bytes = want;
+    return VIT_HIP_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int read_soft(const void* p, size_t idx, int soft_bytes) {
+    return soft_bytes == 1 ? (int)((const int8_t*)p)[idx] : (int)((const int16_t*)p)[idx];
+}
+
+unsigned parity_u32(uint32_t x) { return (unsigned)__builtin_popcount(x) & 1u; }
+
+}  // namespace
+
+extern "C" {
+
+const char* vit_hip_last_error(void) { return g_last_error.c_str(); }
+
+int vit_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+                   int device, vit_hip_handle* out) {
+    if (!out) return fail(VIT_HIP_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "branch_table/config is NULL");
+    if (K < 2 || K > 15) return fail(VIT_HIP_ERR_UNSUPPORTED, "constraint length K must be 2..15 (2^(K-1) u16 metrics x2 in LDS)");
+    if (R < 1 || R > 8) return fail(VIT_HIP_ERR_UNSUPPORTED, "code rate R must be 1..8");
+    if (!((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "(soft_t,error_t) must be (int16_t,uint16_t) or (int8_t,uint8_t)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(VIT_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU decode path)");
+    if (device < 0 || device >= ndev) return fail(VIT_HIP_ERR_INVALID_ARG, "device index out of range");
+
+    vit_hip_decoder* h = new vit_hip_decoder();
+    h->K = K; h->R = R; h->soft_bytes = soft_bytes; h->error_bytes = error_bytes; h->device = device;
+    h->N = 1 << (K - 1); h->H = h->N / 2; h->W = h->N >= 64 ? h->N / 64 : 1;
+    h->shift = soft_bytes == 1 ? 8 : 0;
+    const int Ht = h->H > 0 ? h->H : 1;   // K=2 still stores one half-state
+
+    // the table is two-valued: low == value at half-state 0 (parity of 0 is 0), high == the other value
+    const int low = read_soft(branch_table, 0, soft_bytes);
+    int high = low;
+    bool have_high = false;
+    for (int i = 0; i < R; ++i)
+        for (int s = 0; s < Ht; ++s) {
+            const int v = read_soft(branch_table, (size_t)i * Ht + s, soft_bytes);
+            if (v != low) {
+                if (!have_high) { high = v; have_high = true; }
+                else if (v != high) { delete h; return fail(VIT_HIP_ERR_INVALID_ARG, "branch table holds more than two distinct values"); }
+            }
+        }
+    for (int i = 0; i < R; ++i)
+        if (read_soft(branch_table, (size_t)i * Ht, soft_bytes) != low) {
+            delete h;
+            return fail(VIT_HIP_ERR_INVALID_ARG, "branch table row does not start with the low value");
+        }
+    if (!have_high) high = low;  // degenerate code: every expected symbol is `low`
+    h->high = high; h->low = low;
+    h->pattern.assign(Ht, 0);
+    for (int i = 0; i < R; ++i)
+        for (int s = 0; s < Ht; ++s)
+            if (have_high && read_soft(branch_table, (size_t)i * Ht + s, soft_bytes) == high) h->pattern[s] |= (uint16_t)(1u << i);
+
+    // recover the polynomials (middle bits from the unit half-states; bit 0 and bit K-1 are implied by the butterfly
+    // identity the reference relies on, viterbi_decoder_scalar.h:85-95) and check that the table is linear
+    for (int i = 0; i < R; ++i) {
+        uint32_t g = 1u | (1u << (K - 1));
+        for (int k = 0; k + 2 < K; ++k)
+            if ((h->pattern[(size_t)1 << k] >> i) & 1u) g |= 1u << (k + 1);
+        h->G[i] = g;
+    }
+    h->linear = true;
+    for (int s = 0; s < Ht && h->linear; ++s)
+        for (int i = 0; i < R; ++i)
+            if (parity_u32(((uint32_t)s << 1) & h->G[i] & ~(1u | (1u << (K - 1)))) != ((h->pattern[s] >> i) & 1u)) { h->linear = false; break; }
+
+    for (int k = 0; k < 4; ++k)
+        h->cfg_raw[k] = error_bytes == 1 ? (uint32_t)((const uint8_t*)config)[k] : (uint32_t)((const uint16_t*)config)[k];
+    h->cfg.max_error = (uint16_t)(h->cfg_raw[0] << h->shift);
+    h->cfg.init_start = (uint16_t)(h->cfg_raw[1] << h->shift);
+    h->cfg.init_non_start = (uint16_t)(h->cfg_raw[2] << h->shift);
+    h->cfg.threshold = (uint16_t)(h->cfg_raw[3] << h->shift);
+    h->cfg.high = (int16_t)(uint16_t)((uint32_t)high << h->shift);
+    h->cfg.low = (int16_t)(uint16_t)((uint32_t)low << h->shift);
+
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete h; return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed"); }
+    if (hipMalloc((void**)&h->d_pattern, Ht * sizeof(uint16_t)) != hipSuccess ||
+        hipMemcpy(h->d_pattern, h->pattern.data(), Ht * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (h->d_pattern) (void)hipFree(h->d_pattern);
+        delete h;
+        return fail(VIT_HIP_ERR_RUNTIME, "device allocation failed in vit_hip_create");
+    }
+    h->reg_ok = h->linear && vit::reg_code_supported(K, R) && vit::reg_code_init(&h->reg_code, K, R, h->G, h->cfg);
+    h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : VIT_HIP_PLAN_LDS;
+    *out = h;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_destroy(vit_hip_handle h) {
+    if (!h) return VIT_HIP_OK;
+    DeviceGuard guard(h->device);
+    if (h->d_pattern) (void)hipFree(h->d_pattern);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
+    if (!h || !info) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    memset(info, 0, sizeof(*info));
+    info->K = h->K; info->R = h->R; info->soft_bytes = h->soft_bytes; info->error_bytes = h->error_bytes;
+    info->num_states = h->N; info->decision_words = h->W; info->device = h->device; info->plan = h->plan;
+    info->soft_decision_high = h->high; info->soft_decision_low = h->low;
+    for (int i = 0; i < h->R && i < 16; ++i) info->polynomials[i] = h->linear ? h->G[i] : 0u;
+    info->table_is_linear = h->linear ? 1 : 0;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_set_plan(vit_hip_handle h, int plan) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : VIT_HIP_PLAN_LDS;
+    if (plan == VIT_HIP_PLAN_REG && !h->reg_ok)
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG serves only the register-resident instantiations (see kernels_reg.hpp)");
+    if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG) return fail(VIT_HIP_ERR_INVALID_ARG, "unknown plan");
+    h->plan = plan;
+    return VIT_HIP_OK;
+}
+
+size_t vit_hip_blob_bytes(int K, int R, int soft_bytes, int error_bytes) {
+    if (K < 2 || K > 30 || R < 1) return 0;
+    const size_t Ht = K > 2 ? ((size_t)1 << (K - 2)) : 1;
+    return sizeof(BlobHeader) + (size_t)R * Ht * (size_t)soft_bytes + 4 * (size_t)error_bytes;
+}
+
+int vit_hip_pack_blob(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+                      void* blob, size_t blob_bytes) {
+    const size_t need = vit_hip_blob_bytes(K, R, soft_bytes, error_bytes);
+    if (!need || !branch_table || !config || !blob) return fail(VIT_HIP_ERR_INVALID_ARG, "bad blob arguments");
+    if (blob_bytes < need) return fail(VIT_HIP_ERR_INVALID_ARG, "blob buffer too small");
+    BlobHeader hd{BLOB_MAGIC, K, R, soft_bytes, error_bytes};
+    uint8_t* p = (uint8_t*)blob;
+    memcpy(p, &hd, sizeof(hd));
+    const size_t tb = need - sizeof(hd) - 4 * (size_t)error_bytes;
+    memcpy(p + sizeof(hd), branch_table, tb);
+    memcpy(p + sizeof(hd) + tb, config, 4 * (size_t)error_bytes);
+    return VIT_HIP_OK;
+}
+
+int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vit_hip_handle* out) {
+    if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(VIT_HIP_ERR_INVALID_ARG, "blob too small");
+    BlobHeader hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != BLOB_MAGIC) return fail(VIT_HIP_ERR_INVALID_ARG, "bad blob magic");
+    const size_t need = vit_hip_blob_bytes(hd.K, hd.R, hd.soft_bytes, hd.error_bytes);
+    if (!need || blob_bytes < need) return fail(VIT_HIP_ERR_INVALID_ARG, "blob truncated");
+    const uint8_t* p = (const uint8_t*)blob + sizeof(hd);
+    const size_t tb = need - sizeof(hd) - 4 * (size_t)hd.error_bytes;
+    // copies keep the caller free of alignment requirements
+    std::vector<uint16_t> table((tb + 1) / 2), cfg(4);
+    memcpy(table.data(), p, tb);
+    memcpy(cfg.data(), p + tb, 4 * (size_t)hd.error_bytes);
+    return vit_hip_create(hd.K, hd.R, hd.soft_bytes, hd.error_bytes, table.data(), cfg.data(), device, out);
+}
+
+size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L) {
+    if (!h) return 0;
+    if (h->plan == VIT_HIP_PLAN_REG) return vit::reg_workspace_bytes(h->reg_code, frames, L);
+    return align_up(frames * (L + (size_t)h->K - 1) * (size_t)h->W * 8, 256);
+}
+
+int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t L,
+                         void* d_workspace, size_t workspace_bytes, void* d_final_metrics, uint64_t* d_renorm_sum,
+                         const uint32_t* d_start_state, vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0) return VIT_HIP_OK;
+    if (!d_symbols || !d_workspace) return fail(VIT_HIP_ERR_INVALID_ARG, "d_symbols/d_workspace is NULL");
+    if (n_steps > L + (size_t)h->K - 1) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps exceeds traceback length + K-1");
+    if (n_steps > 0x7FFFFFF0u || frames > 0x7FFFFFF0u) return fail(VIT_HIP_ERR_INVALID_ARG, "batch too large");
+    if (workspace_bytes < vit_hip_workspace_bytes(h, frames, L)) return fail(VIT_HIP_ERR_WORKSPACE, "workspace too small");
+    if (((uintptr_t)d_workspace & 255u) != 0) return fail(VIT_HIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (h->soft_bytes == 2 && ((uintptr_t)d_symbols & 1u)) return fail(VIT_HIP_ERR_INVALID_ARG, "int16 symbols must be 2-byte aligned");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->plan == VIT_HIP_PLAN_REG) {
+        const int rc = vit::reg_update(h->reg_code, h->cfg, h->shift, d_symbols, frames, n_steps, L, d_workspace,
+                                       d_final_metrics, d_renorm_sum, d_start_state, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan update launch failed");
+        return VIT_HIP_OK;
+    }
+    return lds_update(h, d_symbols, frames, n_steps, L + (size_t)h->K - 1, 0, (uint64_t*)d_workspace, d_final_metrics,
+                      true, d_renorm_sum, d_start_state, st);
+}
+
+int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0 || L == 0) return VIT_HIP_OK;
+    if (!d_workspace || !d_bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "d_workspace/d_bytes_out is NULL");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->plan == VIT_HIP_PLAN_REG) {
+        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
+        return VIT_HIP_OK;
+    }
+    return lds_chainback(h, (const uint64_t*)d_workspace, frames, L, d_bytes_out, d_end_state, st);
+}
+
+int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t L, void* d_workspace,
+                         size_t workspace_bytes, uint8_t* d_bytes_out, void* d_final_metrics, uint64_t* d_renorm_sum,
+                         const uint32_t* d_end_state, vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    const int rc = vit_hip_update_batch(h, d_symbols, frames, L + (size_t)h->K - 1, L, d_workspace, workspace_bytes,
+                                        d_final_metrics, d_renorm_sum, nullptr, stream);
+    if (rc != VIT_HIP_OK) return rc;
+    return vit_hip_chainback_batch(h, d_workspace, frames, L, d_bytes_out, d_end_state, stream);
+}
+
+int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t frames, size_t n_steps, size_t L,
+                             uint64_t* d_decisions, vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0 || n_steps == 0) return VIT_HIP_OK;
+    if (!d_workspace || !d_decisions) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL buffer");
+    if (n_steps > L + (size_t)h->K - 1) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps exceeds traceback length + K-1");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->plan == VIT_HIP_PLAN_REG) {
+        const int rc = vit::reg_export(h->reg_code, d_workspace, frames, n_steps, L, d_decisions, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan export launch failed");
+        return VIT_HIP_OK;
+    }
+    const size_t rows = L + (size_t)h->K - 1;
+    const size_t W8 = (size_t)h->W * 8;
+    VIT_HIP_CHECK(hipMemcpy2DAsync(d_decisions, n_steps * W8, d_workspace, rows * W8, n_steps * W8, frames,
+                                   hipMemcpyDeviceToDevice, st));
+    return VIT_HIP_OK;
+}
+
+int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps,
+                        uint64_t* decisions_out, uint64_t* renorm_sum_out) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (!metrics_inout) return fail(VIT_HIP_ERR_INVALID_ARG, "metrics_inout is NULL");
+    if (renorm_sum_out) *renorm_sum_out = 0;
+    if (n_steps == 0) return VIT_HIP_OK;
+    if (!symbols || !decisions_out) return fail(VIT_HIP_ERR_INVALID_ARG, "symbols/decisions_out is NULL");
+    if (n_steps > 0x7FFFFFF0u) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps too large");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    const size_t sym_b = align_up(n_steps * (size_t)h->R * (size_t)h->soft_bytes, 256);
+    const size_t dec_b = align_up(n_steps * (size_t)h->W * 8, 256);
+    const size_t met_b = align_up((size_t)h->N * (size_t)h->error_bytes, 256);
+    int rc = ensure_scratch(h, sym_b + dec_b + met_b + 256);
+    if (rc != VIT_HIP_OK) return rc;
+    uint8_t* base = (uint8_t*)h->d_scratch;
+    uint8_t* d_sym = base;
+    uint64_t* d_dec = (uint64_t*)(base + sym_b);
+    uint8_t* d_met = base + sym_b + dec_b;
+    uint64_t* d_rs = (uint64_t*)(base + sym_b + dec_b + met_b);
+    VIT_HIP_CHECK(hipMemcpyAsync(d_sym, symbols, n_steps * (size_t)h->R * (size_t)h->soft_bytes, hipMemcpyHostToDevice, h->stream));
+    VIT_HIP_CHECK(hipMemcpyAsync(d_met, metrics_inout, (size_t)h->N * (size_t)h->error_bytes, hipMemcpyHostToDevice, h->stream));
+    // streaming state lives on the host between calls, so this route always runs the LDS plan on one frame
+    rc = lds_update(h, d_sym, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
+    if (rc != VIT_HIP_OK) return rc;
+    uint64_t rs = 0;
+    VIT_HIP_CHECK(hipMemcpyAsync(decisions_out, d_dec, n_steps * (size_t)h->W * 8, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipMemcpyAsync(metrics_inout, d_met, (size_t)h->N * (size_t)h->error_bytes, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipMemcpyAsync(&rs, d_rs, 8, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (renorm_sum_out) *renorm_sum_out = rs;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L, size_t end_state, uint8_t* bytes_out) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (L == 0) return VIT_HIP_OK;
+    if (!decisions || !bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL buffer");
+    if (end_state >= (size_t)h->N) return fail(VIT_HIP_ERR_INVALID_ARG, "end_state out of range");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    const size_t rows = L + (size_t)h->K - 1;
+    const size_t dec_b = align_up(rows * (size_t)h->W * 8, 256);
+    const size_t out_b = align_up((L + 7) / 8, 256);
+    int rc = ensure_scratch(h, dec_b + out_b + 256);
+    if (rc != VIT_HIP_OK) return rc;
+    uint8_t* base = (uint8_t*)h->d_scratch;
+    uint32_t es = (uint32_t)end_state;
+    uint32_t* d_es = (uint32_t*)(base + dec_b + out_b);
+    VIT_HIP_CHECK(hipMemcpyAsync(base, decisions, rows * (size_t)h->W * 8, hipMemcpyHostToDevice, h->stream));
+    VIT_HIP_CHECK(hipMemcpyAsync(d_es, &es, 4, hipMemcpyHostToDevice, h->stream));
+    rc = lds_chainback(h, (const uint64_t*)base, 1, L, base + dec_b, d_es, h->stream);
+    if (rc != VIT_HIP_OK) return rc;
+    VIT_HIP_CHECK(hipMemcpyAsync(bytes_out, base + dec_b, (L + 7) / 8, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return VIT_HIP_OK;
+}
+
+}  // extern "C"

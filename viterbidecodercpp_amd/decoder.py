@@ -1,0 +1,307 @@
+"""Host-side mirror of the reference's decoder interface, over the C ABI (include/vit_hip.h).
+
+Names, argument meaning and call pattern follow the reference so that tests read like its own:
+
+    table  = ViterbiBranchTable(K, R, G, soft_decision_high, soft_decision_low, soft_dtype)   # viterbi_branch_table.h:34
+    vitdec = ViterbiDecoder_Core(table, config)                                               # viterbi_decoder_core.h:170
+    vitdec.set_traceback_length(total_input_bits); vitdec.reset()                             # :180, :202
+    acc = ViterbiDecoder_HIP.update(vitdec, symbols)                                          # viterbi_decoder_scalar.h:29
+    err = acc + vitdec.get_error(); data = vitdec.chainback(total_input_bits)                 # core.h:195, :214
+
+`ViterbiDecoder_HIP` is the GPU decoder strategy (the counterpart of ViterbiDecoder_Scalar / _AVX_u16 ...): update() and
+chainback() run as HIP kernels on gfx950; nothing here decodes on the CPU.  `BatchDecoder` is the throughput route:
+many independent frames, device-resident tensors, explicit stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .codes import DecoderConfig
+
+
+def _parity(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    x ^= x >> 16
+    x ^= x >> 8
+    x ^= x >> 4
+    x ^= x >> 2
+    x ^= x >> 1
+    return (x & 1).astype(np.uint8)
+
+
+class ViterbiBranchTable:
+    """Expected symbol value for each half-state and polynomial: bt[i][s] = parity((s << 1) & G[i]) ? high : low
+    (include/viterbi/viterbi_branch_table.h:44-54).  Shareable between decoders (README.md:14)."""
+
+    def __init__(self, K: int, R: int, G, soft_decision_high: int, soft_decision_low: int, soft_dtype=np.int16):
+        if K < 2 or R < 1:
+            raise ValueError("K >= 2 and R >= 1 required")
+        if len(G) != R:
+            raise ValueError("need exactly R polynomials")
+        if not soft_decision_high > soft_decision_low:
+            raise ValueError("soft_decision_high must exceed soft_decision_low")
+        self.K, self.R, self.G = K, R, tuple(int(g) for g in G)
+        self.soft_decision_high, self.soft_decision_low = int(soft_decision_high), int(soft_decision_low)
+        self.soft_dtype = np.dtype(soft_dtype)
+        self.NUMSTATES = max((1 << (K - 1)) // 2, 1)
+        s = np.arange(self.NUMSTATES, dtype=np.uint32) << 1
+        rows = [np.where(_parity(s & np.uint32(g)) != 0, self.soft_decision_high, self.soft_decision_low) for g in self.G]
+        self._table = np.ascontiguousarray(np.stack(rows).astype(self.soft_dtype))
+
+    def __getitem__(self, index):
+        return self._table[index]
+
+    def data(self) -> np.ndarray:
+        return self._table
+
+
+@dataclass
+class ViterbiDecoder_Config:
+    """include/viterbi/viterbi_decoder_config.h:11-18 (+ the error_t width)."""
+    soft_decision_max_error: int
+    initial_start_error: int
+    initial_non_start_error: int
+    renormalisation_threshold: int
+    error_dtype: object = np.uint16
+
+    @classmethod
+    def from_decoder_config(cls, c: DecoderConfig):
+        return cls(c.soft_decision_max_error, c.initial_start_error, c.initial_non_start_error,
+                   c.renormalisation_threshold, c.error_dtype)
+
+    def as_array(self):
+        return np.asarray([self.soft_decision_max_error, self.initial_start_error, self.initial_non_start_error,
+                           self.renormalisation_threshold], dtype=self.error_dtype)
+
+
+class _Handle:
+    def __init__(self, table: ViterbiBranchTable, config: ViterbiDecoder_Config, device: int = 0, blob: bytes = None):
+        L = _lib.load()
+        self._h = C.c_void_p()
+        if blob is not None:
+            buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+            _lib.check(L.vit_hip_create_from_blob(buf, len(blob), device, C.byref(self._h)))
+        else:
+            cfg = config.as_array()
+            edt = np.dtype(config.error_dtype)
+            if (table.soft_dtype.itemsize, edt.itemsize) not in ((2, 2), (1, 1)):
+                raise ValueError("(soft_t, error_t) must be (int16, uint16) or (int8, uint8)")
+            _lib.check(L.vit_hip_create(table.K, table.R, table.soft_dtype.itemsize, edt.itemsize,
+                                        table.data().ctypes.data_as(C.c_void_p), cfg.ctypes.data_as(C.c_void_p), device,
+                                        C.byref(self._h)))
+        self.info = _lib.VitHipInfo()
+        _lib.check(L.vit_hip_get_info(self._h, C.byref(self.info)))
+
+    def refresh(self):
+        _lib.check(_lib.load().vit_hip_get_info(self._h, C.byref(self.info)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().vit_hip_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def pack_blob(table: ViterbiBranchTable, config: ViterbiDecoder_Config) -> bytes:
+    """table + config as the byte blob rank 0 broadcasts to the other GPUs (vit_hip_pack_blob)."""
+    L = _lib.load()
+    edt = np.dtype(config.error_dtype)
+    n = L.vit_hip_blob_bytes(table.K, table.R, table.soft_dtype.itemsize, edt.itemsize)
+    buf = (C.c_uint8 * n)()
+    cfg = config.as_array()
+    _lib.check(L.vit_hip_pack_blob(table.K, table.R, table.soft_dtype.itemsize, edt.itemsize,
+                                   table.data().ctypes.data_as(C.c_void_p), cfg.ctypes.data_as(C.c_void_p), buf, n))
+    return bytes(buf)
+
+
+class ViterbiDecoder_Core:
+    """Decoder state with the reference's public surface (viterbi_decoder_core.h:157-243): m_metrics, m_decisions and
+    m_current_decoded_bit are host-visible; update() and chainback() execute on the GPU."""
+
+    def __init__(self, branch_table: ViterbiBranchTable, config: ViterbiDecoder_Config, device: int = 0):
+        self.m_branch_table = branch_table
+        self.m_config = config
+        self.K, self.R = branch_table.K, branch_table.R
+        self.TOTAL_STATE_BITS = self.K - 1
+        self.NUMSTATES = 1 << (self.K - 1)
+        self.TOTAL_BLOCKS = max(self.NUMSTATES // 64, 1)
+        self._handle = _Handle(branch_table, config, device)
+        self.m_metrics = np.zeros(self.NUMSTATES, dtype=config.error_dtype)
+        self.m_decisions = np.zeros((0, self.TOTAL_BLOCKS), dtype=np.uint64)
+        self.m_current_decoded_bit = 0
+        self.reset()
+        self.set_traceback_length(0)
+
+    def set_traceback_length(self, traceback_length: int):
+        new_length = traceback_length + self.TOTAL_STATE_BITS
+        old = self.m_decisions
+        self.m_decisions = np.zeros((new_length, self.TOTAL_BLOCKS), dtype=np.uint64)
+        n = min(len(old), new_length)
+        self.m_decisions[:n] = old[:n]
+        if self.m_current_decoded_bit > new_length:
+            self.m_current_decoded_bit = new_length
+
+    def get_traceback_length(self) -> int:
+        return len(self.m_decisions) - self.TOTAL_STATE_BITS
+
+    def get_error(self, end_state: int = 0) -> int:
+        assert end_state < self.NUMSTATES
+        return int(self.m_metrics[end_state])
+
+    def reset(self, starting_state: int = 0):
+        self.m_current_decoded_bit = 0
+        self.m_metrics[:] = self.m_config.initial_non_start_error
+        self.m_metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
+
+    def chainback(self, total_bits: int, end_state: int = 0) -> np.ndarray:
+        assert self.get_traceback_length() >= total_bits
+        assert self.m_current_decoded_bit - self.TOTAL_STATE_BITS >= total_bits
+        assert end_state < self.NUMSTATES
+        out = np.zeros((total_bits + 7) // 8, dtype=np.uint8)
+        rows = np.ascontiguousarray(self.m_decisions[:total_bits + self.TOTAL_STATE_BITS])
+        _lib.check(_lib.load().vit_hip_chainback_host(self._handle._h, rows.ctypes.data_as(C.c_void_p), total_bits,
+                                                      end_state, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class ViterbiDecoder_HIP:
+    """The MI355X decoder strategy: same concept as ViterbiDecoder_Scalar (static update(), is_valid)."""
+    is_valid = True
+
+    @staticmethod
+    def update(base: ViterbiDecoder_Core, symbols) -> int:
+        cfg = base.m_config
+        symbols = np.ascontiguousarray(symbols, dtype=base.m_branch_table.soft_dtype).reshape(-1)
+        N = symbols.size
+        assert N % base.R == 0
+        total_decoded_bits = N // base.R
+        max_decoded_bits = base.get_traceback_length() + base.TOTAL_STATE_BITS
+        assert total_decoded_bits + base.m_current_decoded_bit <= max_decoded_bits
+        if total_decoded_bits == 0:
+            return 0
+        rows = np.zeros((total_decoded_bits, base.TOTAL_BLOCKS), dtype=np.uint64)
+        rs = C.c_uint64(0)
+        _lib.check(_lib.load().vit_hip_update_host(base._handle._h, base.m_metrics.ctypes.data_as(C.c_void_p),
+                                                   symbols.ctypes.data_as(C.c_void_p), total_decoded_bits,
+                                                   rows.ctypes.data_as(C.c_void_p), C.byref(rs)))
+        c = base.m_current_decoded_bit
+        base.m_decisions[c:c + total_decoded_bits] = rows
+        base.m_current_decoded_bit = c + total_decoded_bits
+        return int(rs.value)
+
+
+class BatchDecoder:
+    """Frame-parallel decoder on device-resident torch tensors (vit_hip_*_batch).  torch is plumbing only: it owns the
+    HBM buffers and the stream."""
+
+    def __init__(self, branch_table: ViterbiBranchTable = None, config: ViterbiDecoder_Config = None, device=0,
+                 blob: bytes = None, plan: int = _lib.PLAN_AUTO):
+        import torch
+
+        self.torch = torch
+        self.device_index = device if isinstance(device, int) else torch.device(device).index or 0
+        self.device = torch.device("cuda", self.device_index)
+        self._handle = _Handle(branch_table, config, self.device_index, blob=blob)
+        if plan != _lib.PLAN_AUTO:
+            self.set_plan(plan)
+        i = self._handle.info
+        self.K, self.R, self.N, self.W = i.K, i.R, i.num_states, i.decision_words
+        self.soft_bytes, self.error_bytes = i.soft_bytes, i.error_bytes
+        self._ws = None
+
+    @property
+    def plan(self) -> int:
+        return self._handle.info.plan
+
+    def set_plan(self, plan: int):
+        _lib.check(_lib.load().vit_hip_set_plan(self._handle._h, plan))
+        self._handle.refresh()
+
+    def workspace_bytes(self, frames: int, L: int) -> int:
+        return _lib.load().vit_hip_workspace_bytes(self._handle._h, frames, L)
+
+    def _workspace(self, frames, L):
+        need = self.workspace_bytes(frames, L)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        assert self._ws.data_ptr() % 256 == 0
+        return self._ws
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_symbols(self, symbols, n_steps):
+        t = self.torch
+        want = t.int16 if self.soft_bytes == 2 else t.int8
+        if symbols.dtype != want or not symbols.is_cuda or not symbols.is_contiguous():
+            raise ValueError(f"symbols must be a contiguous {want} CUDA tensor")
+        frames = symbols.shape[0]
+        if symbols.numel() != frames * n_steps * self.R:
+            raise ValueError("symbols must have shape [frames][n_steps][R]")
+        return frames
+
+    def update(self, symbols, L: int, n_steps: int = None, start_state=None, want_metrics=True):
+        """reset + update over n_steps (default L+K-1) steps.  returns (final_metrics [F][N], renorm_sum [F])."""
+        t = self.torch
+        n_steps = (L + self.K - 1) if n_steps is None else n_steps
+        frames = self._check_symbols(symbols, n_steps)
+        ws = self._workspace(frames, L)
+        edt = t.int16 if self.error_bytes == 2 else t.uint8  # int16 carries the uint16 bit pattern
+        met = t.empty((frames, self.N), dtype=edt, device=self.device) if want_metrics else None
+        rs = t.empty(frames, dtype=t.int64, device=self.device)
+        ss = None
+        if start_state is not None:
+            ss = t.as_tensor(start_state, dtype=t.int32, device=self.device).contiguous()
+        _lib.check(_lib.load().vit_hip_update_batch(
+            self._handle._h, C.c_void_p(symbols.data_ptr()), frames, n_steps, L, C.c_void_p(ws.data_ptr()), ws.numel(),
+            C.c_void_p(met.data_ptr()) if met is not None else None, C.c_void_p(rs.data_ptr()),
+            C.c_void_p(ss.data_ptr()) if ss is not None else None, self._stream()))
+        self._last = (frames, L, n_steps)
+        return met, rs
+
+    def chainback(self, frames: int, L: int, end_state=None, out=None):
+        t = self.torch
+        ws = self._workspace(frames, L)
+        if out is None:
+            out = t.empty((frames, (L + 7) // 8), dtype=t.uint8, device=self.device)
+        es = None
+        if end_state is not None:
+            es = t.as_tensor(end_state, dtype=t.int32, device=self.device).contiguous()
+        _lib.check(_lib.load().vit_hip_chainback_batch(self._handle._h, C.c_void_p(ws.data_ptr()), frames, L,
+                                                       C.c_void_p(out.data_ptr()),
+                                                       C.c_void_p(es.data_ptr()) if es is not None else None, self._stream()))
+        return out
+
+    def decode(self, symbols, L: int, out=None, want_metrics=False):
+        """reset -> update -> chainback for every frame; returns bytes [F][L/8] (+ metrics, renorm when asked)."""
+        t = self.torch
+        frames = self._check_symbols(symbols, L + self.K - 1)
+        ws = self._workspace(frames, L)
+        if out is None:
+            out = t.empty((frames, (L + 7) // 8), dtype=t.uint8, device=self.device)
+        edt = t.int16 if self.error_bytes == 2 else t.uint8  # int16 carries the uint16 bit pattern
+        met = t.empty((frames, self.N), dtype=edt, device=self.device) if want_metrics else None
+        rs = t.empty(frames, dtype=t.int64, device=self.device) if want_metrics else None
+        _lib.check(_lib.load().vit_hip_decode_batch(
+            self._handle._h, C.c_void_p(symbols.data_ptr()), frames, L, C.c_void_p(ws.data_ptr()), ws.numel(),
+            C.c_void_p(out.data_ptr()), C.c_void_p(met.data_ptr()) if met is not None else None,
+            C.c_void_p(rs.data_ptr()) if rs is not None else None, None, self._stream()))
+        self._last = (frames, L, L + self.K - 1)
+        return (out, met, rs) if want_metrics else out
+
+    def export_decisions(self, frames: int, L: int, n_steps: int = None):
+        """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words)."""
+        t = self.torch
+        n_steps = (L + self.K - 1) if n_steps is None else n_steps
+        ws = self._workspace(frames, L)
+        dec = t.empty((frames, n_steps, self.W), dtype=t.int64, device=self.device)
+        _lib.check(_lib.load().vit_hip_export_decisions(self._handle._h, C.c_void_p(ws.data_ptr()), frames, n_steps, L,
+                                                        C.c_void_p(dec.data_ptr()), self._stream()))
+        return dec
