@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the Viterbi update()+chainback() hot path on MI355X.
+
+One "step" = one pass of the hot path (reset -> update -> chainback) over one batch of synthetic AWGN frames already
+resident in HBM.  Workload at N=1: BASELINE.json configs[1] -- Voyager K=7 R=1/2, u16 error metrics / s16 soft symbols,
+65536 frames x 8192 info bits.  With --gpus N the frames of every rank are independent (weak scaling: each GPU decodes its
+own 65536 frames); the only collective is the broadcast of the branch-table/config blob from rank 0 at set-up (RCCL).
+
+Prints ONE JSON line on rank 0 (see the contract in the round prompt): value = decoded info Mbit/s over all GPUs.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU")
+    ap.add_argument("--bits", type=int, default=8192, help="info bits per frame (L)")
+    ap.add_argument("--code", type=int, default=2, help="index into COMMON_CODES (2 = Voyager K=7 R=1/2)")
+    ap.add_argument("--decode-type", default="SOFT16")
+    ap.add_argument("--ebn0", type=float, default=3.0)
+    ap.add_argument("--plan", default="auto", choices=["auto", "lds", "reg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(code_id, code, pc, decode_type, sym_host, tx_host, L, target_seconds):
+    """The reference's own AVX2 strategy (oracle/_ref, kind "reference") on all host cores over a bounded sample of the
+    same frames; falls back to the C restatement (kind "port", scalar) where _ref was never built."""
+    import numpy as np
+    from oracle import pyoracle
+
+    pyoracle.ensure_built()
+    dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[decode_type]
+    ocfg = pyoracle.stock_config(dt, code.R)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    frames = sym_host.shape[0]
+    bits = frames * L
+    res = {}
+    if pyoracle.RefLib.available():
+        ref = pyoracle.RefLib()
+        simd = pyoracle.SIMD_AVX if ref.is_valid(code_id, pc.soft_bytes, pyoracle.SIMD_AVX) else pyoracle.SCALAR
+        t1, out = ref.bench(code_id, ocfg, sym_host, frames, L, simd=simd, threads=cores, reps=1)
+        reps = max(1, min(2000, int(target_seconds / max(t1, 1e-3))))
+        t, out = ref.bench(code_id, ocfg, sym_host, frames, L, simd=simd, threads=cores, reps=reps)
+        # single-thread scalar (the parity reference) on a slice, for context
+        ns = max(1, min(frames, 64))
+        ts, out_s = ref.bench(code_id, ocfg, sym_host[:ns], ns, L, simd=pyoracle.SCALAR, threads=1, reps=1)
+        res = {"value": bits / t / 1e6, "unit": "Mbit/s", "cores": cores, "kind": "reference",
+               "strategy": {pyoracle.SIMD_AVX: "ViterbiDecoder_AVX_u16/u8", pyoracle.SCALAR: "ViterbiDecoder_Scalar"}[simd],
+               "sample": f"{frames} frames x {L} bits of the GPU batch, best of {reps} passes, {cores} threads "
+                         f"(one decoder per thread, shared branch table)",
+               "scalar_1thread_Mbit_s": ns * L / ts / 1e6}
+        scalar_bytes = out_s
+    else:
+        oracle = pyoracle.Oracle()
+        t0 = time.perf_counter()
+        scalar_bytes, _, _ = oracle.decode_frames(code.K, code.R, code.G, ocfg, sym_host, L, threads=cores)
+        t = time.perf_counter() - t0
+        ns = frames
+        res = {"value": bits / t / 1e6, "unit": "Mbit/s", "cores": cores, "kind": "port",
+               "strategy": "oracle/viterbi_oracle.c (scalar restatement)",
+               "sample": f"{frames} frames x {L} bits of the GPU batch, 1 pass, {cores} threads"}
+    return res, scalar_bytes, ns
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, _lib,
+                                       get_decoding_config, pack_blob, synth)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    code = COMMON_CODES[args.code]
+    pc = get_decoding_config(args.decode_type, code.R)
+    F, L = args.frames, args.bits
+    S = L + code.K - 1
+    W = code.decision_words
+
+    # ---- the shared branch table: built on rank 0, broadcast as one small blob (RCCL over xGMI), rebuilt everywhere ----
+    if rank == 0:
+        table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+        config = ViterbiDecoder_Config.from_decoder_config(pc)
+        blob = pack_blob(table, config)
+        n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    else:
+        blob, n = None, torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(n, src=0)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        blob = bytes(buf.cpu().numpy().tobytes())
+    plan = {"auto": _lib.PLAN_AUTO, "lds": _lib.PLAN_LDS, "reg": _lib.PLAN_REG}[args.plan]
+    dec = BatchDecoder(device=local_rank, blob=blob, plan=plan)
+
+    # ---- synthetic frames, generated directly in HBM (not timed) ----
+    tx, sym = synth.make_frames_torch(code, pc, F, L, args.ebn0, seed=1 + rank, device=dev)
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def one_step(ev=None):
+        dec.update(sym, L, want_metrics=False)
+        if ev is not None:
+            ev[1].record()
+        dec.chainback(F, L, out=out)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        one_step(evs[k])
+        evs[k][2].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    cb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+
+    # ---- size-independent parity property at full size: decoded bits vs transmitted bits ----
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
+    bit_errors = int(lut[torch.bitwise_xor(out, tx).long()].sum().item())
+    ber = bit_errors / float(F * L)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_bits = float(F) * L * world * args.steps
+    value = total_bits / elapsed / 1e6
+    sb = pc.soft_bytes
+    upd_bytes = F * (S * code.R * sb + S * W * 8)            # symbols read + decision words written
+    cb_bytes = F * (L * 8 + L // 8)                          # one decision word read per decoded bit + bytes out
+    achieved = upd_bytes / (upd_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{code.name}|{args.decode_type}|{F}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
+            traffic = tj.get(key, {}).get("update_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
+        "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
+        "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type} "
+                               f"({'u16/s16' if sb == 2 else 'u8/s8'}), {F} frames x {L} info bits per GPU, "
+                               f"AWGN Eb/N0={args.ebn0} dB", "frames_per_gpu": F, "bits_per_frame": L,
+                   "plan": _lib.PLAN_NAMES[dec.plan], "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+        "per_gpu_Mbit_s": value / world, "Msym_s": value * code.R,
+        "update_ms": upd_ms, "chainback_ms": cb_ms,
+        "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": upd_bytes},
+        "roofline_end_to_end": {"achieved": (upd_bytes + cb_bytes) / ((upd_ms + cb_ms) * 1e-3) / 1e9, "unit": "GB/s",
+                                "bytes_per_info_bit": (upd_bytes + cb_bytes) / float(F * L)},
+        "ber": ber,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nf = min(F, max(256, 16 * cores))
+        sym_host = sym[:nf].cpu().numpy()
+        tx_host = tx[:nf].cpu().numpy()
+        base, scalar_bytes, ns = cpu_baseline(args.code, code, pc, args.decode_type, sym_host, tx_host, L, args.cpu_seconds)
+        result["cpu_baseline"] = base
+        gpu_bytes = out[:ns].cpu().numpy()
+        result["parity"] = {"frames_checked_vs_scalar_reference": int(ns),
+                            "bit_exact": bool(np.array_equal(gpu_bytes, scalar_bytes))}
+        result["speedup_vs_cpu_baseline"] = value / base["value"]
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

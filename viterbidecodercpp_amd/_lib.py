@@ -47,6 +47,12 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension has not been built (there is no CPU fallback)")
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; importing torch first makes
+    # libvit_hip.so bind to that copy instead of pulling /opt/rocm's in beside it (two runtimes => "no device").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     L.vit_hip_last_error.restype = C.c_char_p

@@ -1,14 +1,623 @@
-// kernels_reg.hpp -- PLAN_REG placeholder (register-resident kernels land in the next commit).
+// kernels_reg.hpp -- PLAN_REG: state metrics resident in VGPRs, 4 lanes per frame PAIR, packed 2x16-bit arithmetic.
+//
+// Device implementation of the reference's scalar strategy for the K = 7 and K = 9 stock codes
+//   ViterbiDecoder_Scalar::update / bfly / renormalise   include/viterbi/viterbi_decoder_scalar.h:29-153
+//   ViterbiDecoder_Core::chainback                       include/viterbi/viterbi_decoder_core.h:214-236
+// Results are bit-identical to PLAN_LDS and to the reference; only the mapping onto the machine differs.
+//
+// Mapping (gfx950, wave64).  One wavefront decodes a TILE of 32 frames.  Lane l = 16*q + g (q = 0..3, g = 0..15) works
+// on the frame pair (A = 32*tile + g, B = A + 16): every VGPR holds one state metric of frame A in its low half and the
+// same state's metric of frame B in its high half, so one v_pk_* instruction advances two frames.  The 2^(K-1) states of
+// a frame are spread over the 4 q-lanes x NREG registers: "slot" x = (q << REG_BITS) | r.
+//
+//   * in-place butterflies by index rotation: at trellis step t (phase ph = t mod (K-1)) state s lives in slot
+//     rotr^ph(s).  The butterfly {(0|X),(1|X)} -> {(X|0),(X|1)} then reads and writes the SAME two slots, which differ in
+//     slot bit p = K-2-ph.  When p is a register bit the step needs no data movement at all; when p is one of the two
+//     lane bits, one v_permlane32_swap / v_permlane16_swap per register pair exchanges that lane bit with the top
+//     register bit before the butterflies and again after them (2 of every K-1 steps).
+//   * branch metrics: the convolutional code is linear, so the R-bit branch pattern of butterfly (q, r) is
+//     pat(r) ^ pat(q); pat(r) is a compile-time constant per register and pat(q) is folded in by swapping |high-y| and
+//     |low-y| per lane with a constant lane mask.  Only 2^R packed error sums E[p] (and max_error - E[p]) exist per step.
+//   * add-compare-select per register pair, exact for wrapping u16 metrics:  s = sat_sub(m_r0, m_r1) is non-zero iff
+//     m_r0 > m_r1 (the reference's strict '>' -- tie keeps r0), min = m_r0 - s, decision bit = min(s, 1).
+//   * u8 metrics / s8 symbols are carried in the HIGH byte of each 16-bit half, which makes 16-bit wrapping arithmetic
+//     reproduce mod-256 arithmetic.
+//   * decision bits: one dword per lane per 16 registers (frame A bits 0-15, frame B bits 16-31), stored as coalesced
+//     16-byte-per-lane rows: ws[tile][step group][lane] (1 KiB per wave store).  Bit order is the slot order of the step
+//     (a rotation of the state index) -- vit_hip_export_decisions() converts to the reference's bit order.
+//   * chainback walks the same layout with the same lane roles: each q-lane extracts the candidate bit of its slice and a
+//     ds_bpermute fetches the one belonging to the survivor state.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
 #include "kernels_lds.hpp"
+
 namespace vit {
-struct RegCode { int K = 0, R = 0; };
-inline bool reg_code_supported(int, int) { return false; }
-inline bool reg_code_init(RegCode*, int, int, const uint32_t*, const DevConfig&) { return false; }
-inline size_t reg_workspace_bytes(const RegCode&, size_t, size_t) { return 0; }
-inline int reg_update(const RegCode&, const DevConfig&, int, const void*, size_t, size_t, size_t, void*, void*, uint64_t*, const uint32_t*, hipStream_t) { return -1; }
-inline int reg_chainback(const RegCode&, const void*, size_t, size_t, uint8_t*, const uint32_t*, hipStream_t) { return -1; }
-inline int reg_export(const RegCode&, const void*, size_t, size_t, size_t, uint64_t*, hipStream_t) { return -1; }
+
+typedef uint32_t u32;
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
+#define VIT_DEV __device__ __forceinline__
+
+VIT_DEV u32 pk_add(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b)));
 }
+VIT_DEV u32 pk_sub(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b)));
+}
+VIT_DEV u32 pk_min_u(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+VIT_DEV u32 pk_max_s(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+// per-half unsigned saturating subtract.  Inline asm on purpose: hipcc's instcombine rewrites min(usub.sat(a,b),1) into
+// two scalar compares + selects + a byte permute, which is 3x the instructions.
+VIT_DEV u32 pk_sub_sat(u32 a, u32 b) {
+    u32 d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// d = lanemask[lane] ? b : a, lanemask a wave-uniform 64-bit constant
+VIT_DEV u32 cnd_mask(u32 a, u32 b, uint64_t lanemask) {
+    u32 d;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(lanemask));
+    return d;
+}
+
+template <class F, int... Is>
+VIT_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+VIT_DEV void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
+
+// ---- compile-time description of one code -------------------------------------------------------------------------
+template <int K_, int R_, u32 G0, u32 G1, u32 G2, u32 G3>
+struct RegSpec {
+    static constexpr int K = K_, R = R_;
+    static constexpr int SB = K - 1;              // state bits
+    static constexpr int REG_BITS = SB - 2;       // two state-slot bits live in the lane index (lane bits 4 and 5)
+    static constexpr int NREG = 1 << REG_BITS;    // packed metric registers per lane
+    static constexpr int DW = NREG >= 16 ? NREG / 16 : 1;  // decision dwords per lane per step
+    static constexpr int SPS = 4 / DW;            // steps per 16-byte decision row
+    static constexpr u32 SMASK = (1u << SB) - 1u;
+    static constexpr u32 G(int i) { return i == 0 ? G0 : i == 1 ? G1 : i == 2 ? G2 : G3; }
+
+    static constexpr u32 rotl(u32 x, int n) {
+        n %= SB;
+        return n == 0 ? (x & SMASK) : (((x << n) | (x >> (SB - n))) & SMASK);
+    }
+    static constexpr u32 rotr(u32 x, int n) { return rotl(x, (SB - (n % SB)) % SB); }
+    static constexpr u32 parity(u32 v) {
+        v ^= v >> 16; v ^= v >> 8; v ^= v >> 4; v ^= v >> 2; v ^= v >> 1;
+        return v & 1u;
+    }
+    // R-bit branch pattern of the half-state-like value v: bit i = parity((v << 1) & G[i])   (viterbi_branch_table.h:48-51)
+    static constexpr u32 pat(u32 v) {
+        u32 p = 0;
+        for (int i = 0; i < R; ++i) p |= parity((v << 1) & G(i)) << i;
+        return p;
+    }
+    // slot bit exchanged by the butterflies of phase ph, and whether that is a lane bit
+    static constexpr int pbit(int ph) { return SB - 1 - ph; }
+    static constexpr bool lane_phase(int ph) { return pbit(ph) >= REG_BITS; }
+    static constexpr int T = REG_BITS - 1;  // register bit a lane bit is exchanged with
+
+    // pattern contributed by the register index r0 (bit of the butterfly cleared) in phase ph
+    static constexpr u32 pat_reg(int ph, u32 r0) { return pat(rotl(r0, ph)); }
+    // pattern contributed by lane group q in phase ph
+    static constexpr u32 pat_lane(int ph, u32 q) {
+        if (!lane_phase(ph)) return pat(rotl(q << REG_BITS, ph));
+        // after the lane<->register exchange: this lane's bit `lb` stands for slot register bit T, the butterfly bit
+        // itself (slot lane bit lb) is 0 for the r0 member; the other lane bit is unchanged
+        const int lb = pbit(ph) - REG_BITS;
+        const u32 u = (q >> lb) & 1u, o = (q >> (1 - lb)) & 1u;
+        u32 x = 0;
+        if (u) x |= 1u << T;
+        if (o) x |= 1u << (REG_BITS + (1 - lb));
+        return pat(rotl(x, ph));
+    }
+    // 64-bit lane mask: lanes whose group q has pattern bit i set in phase ph
+    static constexpr uint64_t lane_mask(int ph, int i) {
+        uint64_t m = 0;
+        for (u32 q = 0; q < 4; ++q)
+            if ((pat_lane(ph, q) >> i) & 1u) m |= 0xFFFFull << (16 * q);
+        return m;
+    }
+};
+
+struct RegUpdateArgs {
+    const uint8_t* symbols;
+    size_t sym_frame_stride_bytes;
+    size_t sym_total_bytes;
+    uint4* ws;
+    size_t ws_tile_stride;  // in uint4 units
+    void* metrics_out;      // [F][N] error_t or null
+    uint64_t* renorm_sum;   // [F] or null
+    const u32* start_state; // [F] or null
+    u32 frames, n_steps;
+    DevConfig cfg;
+};
+
+// 16 bytes of a frame's symbol stream; never reads at or beyond `end`
+VIT_DEV uint4 load_chunk(const uint8_t* base, size_t off, size_t end) {
+    if (off + 16 <= end) {
+        uint4 v;
+        __builtin_memcpy(&v, base + off, 16);
+        return v;
+    }
+    u32 w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k)
+        if (off + k < end) w[k >> 2] |= (u32)base[off + k] << ((k & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <class SP, int SHIFT>
+__global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
+    constexpr int SB = SP::SB, R = SP::R, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS, T = SP::T;
+    constexpr int SBY = SHIFT ? 1 : 2;   // sizeof(soft_t)
+    constexpr int BPS = R * SBY;         // symbol bytes per trellis step per frame
+    // unrolled block: whole phases, whole 16-byte symbol chunks, whole decision rows
+    constexpr int U = clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
+    constexpr int NCH = U * BPS / 16;
+    constexpr int NP = 1 << R;
+
+    const int lane = threadIdx.x & 63;
+    const u32 g = lane & 15, q = lane >> 4;
+    const size_t tile = blockIdx.x;
+    const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
+    const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
+    const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
+    const size_t offA = (size_t)fA * a.sym_frame_stride_bytes, offB = (size_t)fB * a.sym_frame_stride_bytes;
+
+    const u32 HIGH2 = (u32)(uint16_t)a.cfg.high * 0x10001u, LOW2 = (u32)(uint16_t)a.cfg.low * 0x10001u;
+    const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u, THR2 = (u32)a.cfg.threshold * 0x10001u;
+
+    // ---- reset (viterbi_decoder_core.h:202-211): phase 0, slot == state ----
+    u32 m[NREG];
+    {
+        const u32 sA = a.start_state ? (a.start_state[fA] & SP::SMASK) : 0u;
+        const u32 sB = a.start_state ? (a.start_state[fB] & SP::SMASK) : 0u;
+        static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr u32 r = decltype(rc)::value;
+            const u32 x = (q << REG_BITS) | r;
+            const u32 lo = (x == sA) ? a.cfg.init_start : a.cfg.init_non_start;
+            const u32 hi = (x == sB) ? a.cfg.init_start : a.cfg.init_non_start;
+            m[r] = lo | (hi << 16);
+        });
+    }
+
+    uint4 cA[NCH], cB[NCH];
+    static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        cA[c] = load_chunk(a.symbols, offA + 16 * c, a.sym_total_bytes);
+        cB[c] = load_chunk(a.symbols, offB + 16 * c, a.sym_total_bytes);
+    });
+
+    uint64_t rsA = 0, rsB = 0;
+    u32 dq[4] = {0, 0, 0, 0};
+    uint4* ws_tile = a.ws + tile * a.ws_tile_stride;
+
+    for (u32 t0 = 0; t0 < a.n_steps; t0 += U) {
+        static_for<U>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int PH = u % SB;
+            if (t0 + u < a.n_steps) {
+                // ---- symbols of this step, packed (frame A | frame B << 16), in the device's 16-bit domain ----
+                u32 A1[R], A0[R];
+                static_for<R>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int o = u * BPS + i * SBY;
+                    constexpr int c = o / 16, d = (o % 16) / 4, sub = o % 4;
+                    const u32 wa = d == 0 ? cA[c].x : d == 1 ? cA[c].y : d == 2 ? cA[c].z : cA[c].w;
+                    const u32 wb = d == 0 ? cB[c].x : d == 1 ? cB[c].y : d == 2 ? cB[c].z : cB[c].w;
+                    constexpr u32 sel = SHIFT ? (0x0cu | ((u32)sub << 8) | (0x0cu << 16) | ((u32)(4 + sub) << 24))
+                                              : ((u32)sub | ((u32)(sub + 1) << 8) | ((u32)(4 + sub) << 16) | ((u32)(5 + sub) << 24));
+                    const u32 Y = __builtin_amdgcn_perm(wb, wa, sel);
+                    // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71) for expected = high and = low
+                    const u32 d1 = pk_sub(HIGH2, Y), d0 = pk_sub(LOW2, Y);
+                    u32 a1 = pk_max_s(d1, pk_sub(0u, d1)), a0 = pk_max_s(d0, pk_sub(0u, d0));
+                    constexpr uint64_t LM = SP::lane_mask(PH, i);
+                    if constexpr (LM == ~0ull) {
+                        const u32 tmp = a1; a1 = a0; a0 = tmp;
+                    } else if constexpr (LM != 0) {
+                        const u32 t1 = cnd_mask(a1, a0, LM), t0_ = cnd_mask(a0, a1, LM);
+                        a1 = t1; a0 = t0_;
+                    }
+                    A1[i] = a1; A0[i] = a0;
+                });
+                // ---- E[p] = sum_i |bt_i - y_i| for every branch pattern p, and max_error - E[p]  (scalar.h:66-73,107) ----
+                u32 E[NP], EB[NP];
+                static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+                    constexpr int p = decltype(pc)::value;
+                    u32 e = (p & 1) ? A1[0] : A0[0];
+                    static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value + 1;
+                        e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
+                    });
+                    E[p] = e;
+                    EB[p] = pk_sub(MAXE2, e);
+                });
+
+                constexpr bool LP = SP::lane_phase(PH);
+                constexpr int PB = LP ? T : SP::pbit(PH);          // register bit the butterflies pair on
+                constexpr int LB = LP ? SP::pbit(PH) - REG_BITS : 0;
+                auto lane_swap = [&](u32& x0, u32& x1) __attribute__((always_inline)) {
+                    if constexpr (LB == 1) {
+                        auto r2 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+                        x0 = r2[0]; x1 = r2[1];
+                    } else {
+                        auto r2 = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+                        x0 = r2[0]; x1 = r2[1];
+                    }
+                };
+                if constexpr (LP) {
+                    static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
+                        constexpr int r0 = decltype(hc)::value;   // bit T clear because r0 < NREG/2
+                        lane_swap(m[r0], m[r0 | (1 << T)]);
+                    });
+                }
+                // ---- add-compare-select, in place  (scalar.h:113-134) ----
+                u32 acc[DW];
+                u32 acc_hi = 0;  // NREG == 16 lane phases only
+                static_for<DW>([&](auto dc) __attribute__((always_inline)) { acc[decltype(dc)::value] = 0; });
+                static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
+                    constexpr int h = decltype(hc)::value;
+                    // h enumerates the NREG/2 register indices with bit PB clear
+                    constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
+                    constexpr int r1 = r0 | (1 << PB);
+                    constexpr u32 p = SP::pat_reg(PH, (u32)r0);
+                    const u32 ma = m[r0], mb = m[r1];
+                    const u32 x0 = pk_add(ma, E[p]), y0 = pk_add(mb, EB[p]);   // -> next state (X|0)
+                    const u32 x1 = pk_add(ma, EB[p]), y1 = pk_add(mb, E[p]);   // -> next state (X|1)
+                    const u32 s0 = pk_sub_sat(x0, y0), s1 = pk_sub_sat(x1, y1);
+                    m[r0] = pk_sub(x0, s0);
+                    m[r1] = pk_sub(x1, s1);
+                    const u32 b0 = pk_min_u(s0, 0x00010001u), b1 = pk_min_u(s1, 0x00010001u);
+                    if constexpr (LP && NREG == 16) {
+                        acc[0] |= b0 << r0;      // r0 < 8: slots with register bit T == (this lane's bit), lane bit 0
+                        acc_hi |= b1 << r0;      // same positions, slot lane bit 1
+                    } else {
+                        acc[r0 / 16] |= b0 << (r0 % 16);
+                        acc[r1 / 16] |= b1 << (r1 % 16);
+                    }
+                });
+                if constexpr (LP) {
+                    static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
+                        constexpr int r0 = decltype(hc)::value;
+                        lane_swap(m[r0], m[r0 | (1 << T)]);
+                    });
+                    if constexpr (NREG == 16) {
+                        lane_swap(acc[0], acc_hi);
+                        acc[0] |= acc_hi << (1 << T);
+                    } else {
+                        static_for<DW / 2>([&](auto dc) __attribute__((always_inline)) {
+                            constexpr int d = decltype(dc)::value;
+                            lane_swap(acc[d], acc[d + DW / 2]);
+                        });
+                    }
+                }
+                // ---- decision rows: 16 bytes per lane, 1 KiB per wave, coalesced ----
+                if constexpr (DW == 4) {
+                    ws_tile[(size_t)(t0 + u) * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+                    static_for<DW>([&](auto dc) __attribute__((always_inline)) {
+                        constexpr int d = decltype(dc)::value;
+                        dq[(u % SPS) * DW + d] = acc[d];
+                    });
+                    if constexpr (u % SPS == SPS - 1)
+                        ws_tile[(size_t)((t0 + u) / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                }
+                // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153); state 0 is slot 0 ----
+                {
+                    const u32 z = pk_sub_sat(THR2, m[0]);  // half == 0  <=>  metric >= threshold
+                    const bool need = (q == 0) && (((z & 0xFFFFu) == 0) || ((z >> 16) == 0));
+                    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                        const u32 zq = (u32)__shfl((int)z, (int)g);
+                        const u32 msk = (((zq & 0xFFFFu) == 0) ? 0x0000FFFFu : 0u) | (((zq >> 16) == 0) ? 0xFFFF0000u : 0u);
+                        u32 mn = m[0];
+                        static_for<NREG - 1>([&](auto rc) __attribute__((always_inline)) {
+                            mn = pk_min_u(mn, m[decltype(rc)::value + 1]);
+                        });
+                        mn = pk_min_u(mn, (u32)__shfl_xor((int)mn, 16));
+                        mn = pk_min_u(mn, (u32)__shfl_xor((int)mn, 32));
+                        const u32 sub = mn & msk;
+                        static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
+                            constexpr int r = decltype(rc)::value;
+                            m[r] = pk_sub(m[r], sub);
+                        });
+                        rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
+                        rsB += (uint64_t)((sub >> 16) >> SHIFT);
+                    }
+                }
+                // ---- refill symbol chunks whose last reader was this step (data is next needed ~U steps from now) ----
+                static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    constexpr int last_use = (16 * c + 15) / BPS;          // step of this block that reads byte 16c+15
+                    constexpr int first_use = (16 * c) / BPS;
+                    if constexpr (last_use == u) {
+                        if (t0 + U + first_use < a.n_steps) {
+                            const size_t o = (size_t)(t0 + U) * BPS + 16 * c;
+                            cA[c] = load_chunk(a.symbols, offA + o, a.sym_total_bytes);
+                            cB[c] = load_chunk(a.symbols, offB + o, a.sym_total_bytes);
+                        }
+                    }
+                });
+            }
+        });
+    }
+    if constexpr (DW != 4) {
+        if (a.n_steps % SPS != 0) ws_tile[(size_t)(a.n_steps / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+    }
+
+    // ---- final metrics in state order (get_error / m_metrics "old" buffer) ----
+    if (a.metrics_out) {
+        const int ph = (int)(a.n_steps % SB);
+        constexpr size_t N = (size_t)1 << SB;
+        static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr u32 r = decltype(rc)::value;
+            const u32 x = (q << REG_BITS) | r;
+            const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;   // state held by slot x after n_steps steps
+            if (SHIFT) {
+                if (validA) ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((m[r] & 0xFFFFu) >> 8);
+                if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(m[r] >> 24);
+            } else {
+                if (validA) ((uint16_t*)a.metrics_out)[(size_t)fA * N + s] = (uint16_t)(m[r] & 0xFFFFu);
+                if (validB) ((uint16_t*)a.metrics_out)[(size_t)fB * N + s] = (uint16_t)(m[r] >> 16);
+            }
+        });
+    }
+    if (a.renorm_sum && q == 0) {
+        if (validA) a.renorm_sum[fA] = rsA;
+        if (validB) a.renorm_sum[fB] = rsB;
+    }
+}
+
+// ---- chainback on the PLAN_REG layout -----------------------------------------------------------------------------
+struct RegChainbackArgs {
+    const uint4* ws;
+    size_t ws_tile_stride;
+    uint8_t* out;             // [F][ceil(L/8)]
+    const u32* end_state;     // [F] or null
+    u32 frames, L;
+};
+
+template <class SP>
+__global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) {
+    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
+    constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
+    constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
+    constexpr int PF = 8;                                      // decision rows fetched ahead of the dependent chain
+
+    const int lane = threadIdx.x & 63;
+    const u32 g = lane & 15, q = lane >> 4;
+    const size_t tile = blockIdx.x;
+    const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
+    const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
+    const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
+    const uint4* ws_tile = a.ws + tile * a.ws_tile_stride;
+    const size_t out_stride = ((size_t)a.L + 7) / 8;
+    uint8_t* outA = a.out + (size_t)fA * out_stride;
+    uint8_t* outB = a.out + (size_t)fB * out_stride;
+
+    u32 regA = (a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u) << SHIFT_STATE;
+    u32 regB = (a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u) << SHIFT_STATE;
+
+    // rows are consumed from t = L-1 + SB down to SB; row group = t / SPS
+    const int t_hi = (int)a.L - 1 + SB;
+    const int grp_hi = t_hi / SPS, grp_lo = SB / SPS;
+    auto load_row = [&](int grp) -> uint4 {
+        return (grp >= grp_lo) ? ws_tile[(size_t)grp * 64 + lane] : make_uint4(0, 0, 0, 0);
+    };
+    uint4 cur[PF], nxt[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) cur[k] = load_row(grp_hi - k);
+
+    auto trace = [&](u32& reg, u32 w, int half, int ph1) __attribute__((always_inline)) {
+        const u32 state = reg >> SHIFT_STATE;
+        const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
+        const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
+        const u32 mine = (w >> ((rs & 15u) + 16u * half)) & 1u;               // candidate from this lane's slice
+        const u32 bit = (u32)__shfl((int)mine, (int)(qs * 16 + g));           // the slice that owns slot x
+        reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
+    };
+
+    for (int gbase = grp_hi; gbase >= grp_lo; gbase -= PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) nxt[k] = load_row(gbase - PF - k);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int grp = gbase - k;
+            if (grp >= grp_lo) {
+#pragma unroll
+                for (int sidx = SPS - 1; sidx >= 0; --sidx) {
+                    const int t = grp * SPS + sidx;
+                    if (t <= t_hi && t >= SB) {
+                        const int j = t - SB;
+                        const int ph1 = (t + 1) % SB;
+                        if constexpr (DW == 4) {
+                            // dword = slot register index / 16 -- differs per frame, select before the shift
+                            const u32 stA = regA >> SHIFT_STATE, stB = regB >> SHIFT_STATE;
+                            const u32 xA = ((stA >> ph1) | (stA << (SB - ph1))) & SP::SMASK;
+                            const u32 xB = ((stB >> ph1) | (stB << (SB - ph1))) & SP::SMASK;
+                            const u32 dA = (xA & (NREG - 1)) >> 4, dB = (xB & (NREG - 1)) >> 4;
+                            const uint4 v = cur[k];
+                            const u32 wA = dA == 0 ? v.x : dA == 1 ? v.y : dA == 2 ? v.z : v.w;
+                            const u32 wB = dB == 0 ? v.x : dB == 1 ? v.y : dB == 2 ? v.z : v.w;
+                            trace(regA, wA, 0, ph1);
+                            trace(regB, wB, 1, ph1);
+                        } else {
+                            const uint4 v = cur[k];
+                            const u32 w = sidx == 0 ? v.x : sidx == 1 ? v.y : sidx == 2 ? v.z : v.w;
+                            trace(regA, w, 0, ph1);
+                            trace(regB, w, 1, ph1);
+                        }
+                        if ((j & 7) == 0 && q == 0) {
+                            if (validA) outA[j >> 3] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
+                            if (validB) outB[j >> 3] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) cur[k] = nxt[k];
+    }
+}
+
+// ---- export to the reference layout [F][n_steps][W] ----------------------------------------------------------------
+struct RegExportArgs {
+    const u32* ws32;
+    size_t ws_tile_stride;  // uint4 units
+    uint64_t* out;
+    u32 frames, n_steps;
+};
+
+template <class SP>
+__global__ void reg_export_kernel(RegExportArgs a) {
+    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
+    constexpr int W = SB >= 6 ? 1 << (SB - 6) : 1;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (frame, step, word)
+    const size_t total = (size_t)a.frames * a.n_steps * W;
+    if (idx >= total) return;
+    const u32 w = (u32)(idx % W);
+    const u32 t = (u32)((idx / W) % a.n_steps);
+    const u32 f = (u32)(idx / ((size_t)W * a.n_steps));
+    const u32 tile = f / 32, g = f % 16, half = (f % 32) / 16;
+    const int ph1 = (int)((t + 1) % SB);
+    uint64_t word = 0;
+    for (u32 b = 0; b < 64; ++b) {
+        const u32 s = w * 64 + b;
+        if (s > SP::SMASK) break;
+        const u32 x = ((s >> ph1) | (s << (SB - ph1))) & SP::SMASK;
+        const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
+        const size_t row = (size_t)tile * a.ws_tile_stride + (size_t)(t / SPS) * 64 + qs * 16 + g;
+        const u32 dwi = (DW == 4) ? (rs >> 4) : (t % SPS) * DW + (rs >> 4);
+        const u32 v = a.ws32[row * 4 + dwi];
+        word |= (uint64_t)((v >> ((rs & 15u) + 16u * half)) & 1u) << b;
+    }
+    a.out[idx] = word;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+using Spec_K7R2 = RegSpec<7, 2, 109, 79, 0, 0>;             // Voyager          (common_codes.h:23)
+using Spec_K7R3 = RegSpec<7, 3, 91, 117, 121, 0>;           // LTE              (:24)
+using Spec_K7R4 = RegSpec<7, 4, 109, 79, 83, 109>;          // DAB Radio        (:25)
+using Spec_K9R2 = RegSpec<9, 2, 491, 369, 0, 0>;            // CDMA IS-95A      (:26)
+using Spec_K9R4 = RegSpec<9, 4, 501, 441, 331, 315>;        // CDMA 2000        (:27)
+
+struct RegCode {
+    int id = -1;   // 0..4 in the order above
+    int K = 0, R = 0;
+};
+
+inline bool reg_code_supported(int K, int R) { return (K == 7 && R >= 2 && R <= 4) || (K == 9 && (R == 2 || R == 4)); }
+
+inline bool reg_code_init(RegCode* rc, int K, int R, const uint32_t* G, const DevConfig&) {
+    struct Entry { int K, R; uint32_t G[4]; };
+    static const Entry table[5] = {{7, 2, {109, 79, 0, 0}}, {7, 3, {91, 117, 121, 0}}, {7, 4, {109, 79, 83, 109}},
+                                   {9, 2, {491, 369, 0, 0}}, {9, 4, {501, 441, 331, 315}}};
+    for (int id = 0; id < 5; ++id) {
+        if (table[id].K != K || table[id].R != R) continue;
+        bool same = true;
+        for (int i = 0; i < R; ++i) same = same && (table[id].G[i] == G[i]);
+        if (same) { rc->id = id; rc->K = K; rc->R = R; return true; }
+    }
+    return false;
+}
+
+inline size_t reg_groups(const RegCode& rc, size_t L) {
+    const size_t S = L + (size_t)rc.K - 1;
+    const size_t sps = rc.K == 9 ? 1 : 4;
+    return (S + sps - 1) / sps;
+}
+inline size_t reg_tiles(size_t frames) { return (frames + 31) / 32; }
+inline size_t reg_workspace_bytes(const RegCode& rc, size_t frames, size_t L) {
+    return reg_tiles(frames) * reg_groups(rc, L) * 1024;
+}
+
+template <class SP>
+int reg_update_launch(int shift, const RegUpdateArgs& a, size_t tiles, hipStream_t st) {
+    if (shift) hipLaunchKernelGGL((reg_update_kernel<SP, 8>), dim3((unsigned)tiles), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((reg_update_kernel<SP, 0>), dim3((unsigned)tiles), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t frames,
+                      size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start,
+                      hipStream_t st) {
+    if (frames == 0 || n_steps == 0) return 0;
+    RegUpdateArgs a{};
+    a.symbols = (const uint8_t*)d_symbols;
+    a.sym_frame_stride_bytes = n_steps * (size_t)rc.R * (shift ? 1 : 2);
+    a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
+    a.ws = (uint4*)d_ws;
+    a.ws_tile_stride = reg_groups(rc, L) * 64;
+    a.metrics_out = d_metrics;
+    a.renorm_sum = d_renorm;
+    a.start_state = d_start;
+    a.frames = (u32)frames;
+    a.n_steps = (u32)n_steps;
+    a.cfg = cfg;
+    const size_t tiles = reg_tiles(frames);
+    switch (rc.id) {
+        case 0: return reg_update_launch<Spec_K7R2>(shift, a, tiles, st);
+        case 1: return reg_update_launch<Spec_K7R3>(shift, a, tiles, st);
+        case 2: return reg_update_launch<Spec_K7R4>(shift, a, tiles, st);
+        case 3: return reg_update_launch<Spec_K9R2>(shift, a, tiles, st);
+        case 4: return reg_update_launch<Spec_K9R4>(shift, a, tiles, st);
+        default: return -1;
+    }
+}
+
+inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
+                         hipStream_t st) {
+    if (frames == 0 || L == 0) return 0;
+    RegChainbackArgs a{};
+    a.ws = (const uint4*)d_ws;
+    a.ws_tile_stride = reg_groups(rc, L) * 64;
+    a.out = d_out;
+    a.end_state = d_end;
+    a.frames = (u32)frames;
+    a.L = (u32)L;
+    const unsigned tiles = (unsigned)reg_tiles(frames);
+    switch (rc.id) {
+        case 0: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R2>, dim3(tiles), dim3(64), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R3>, dim3(tiles), dim3(64), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R4>, dim3(tiles), dim3(64), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K9R2>, dim3(tiles), dim3(64), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K9R4>, dim3(tiles), dim3(64), 0, st, a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t n_steps, size_t L, uint64_t* d_out,
+                      hipStream_t st) {
+    if (frames == 0 || n_steps == 0) return 0;
+    RegExportArgs a{};
+    a.ws32 = (const u32*)d_ws;
+    a.ws_tile_stride = reg_groups(rc, L) * 64;
+    a.out = d_out;
+    a.frames = (u32)frames;
+    a.n_steps = (u32)n_steps;
+    const size_t W = rc.K == 9 ? 4 : 1;
+    const size_t total = frames * n_steps * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (rc.K == 9) hipLaunchKernelGGL(reg_export_kernel<Spec_K9R2>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(reg_export_kernel<Spec_K7R2>, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace vit

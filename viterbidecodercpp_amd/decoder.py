@@ -247,23 +247,26 @@ class BatchDecoder:
             raise ValueError("symbols must have shape [frames][n_steps][R]")
         return frames
 
-    def update(self, symbols, L: int, n_steps: int = None, start_state=None, want_metrics=True):
-        """reset + update over n_steps (default L+K-1) steps.  returns (final_metrics [F][N], renorm_sum [F])."""
+    def update(self, symbols, L: int, n_steps: int = None, start_state=None, want_metrics=True, metrics_out=None,
+               renorm_out=None):
+        """reset + update over n_steps (default L+K-1) steps.  returns (final_metrics [F][N], renorm_sum [F]);
+        with want_metrics=False and no *_out buffers nothing but the decision workspace is written."""
         t = self.torch
         n_steps = (L + self.K - 1) if n_steps is None else n_steps
         frames = self._check_symbols(symbols, n_steps)
         ws = self._workspace(frames, L)
         edt = t.int16 if self.error_bytes == 2 else t.uint8  # int16 carries the uint16 bit pattern
-        met = t.empty((frames, self.N), dtype=edt, device=self.device) if want_metrics else None
-        rs = t.empty(frames, dtype=t.int64, device=self.device)
+        met, rs = metrics_out, renorm_out
+        if want_metrics:
+            met = t.empty((frames, self.N), dtype=edt, device=self.device) if met is None else met
+            rs = t.empty(frames, dtype=t.int64, device=self.device) if rs is None else rs
         ss = None
         if start_state is not None:
             ss = t.as_tensor(start_state, dtype=t.int32, device=self.device).contiguous()
         _lib.check(_lib.load().vit_hip_update_batch(
             self._handle._h, C.c_void_p(symbols.data_ptr()), frames, n_steps, L, C.c_void_p(ws.data_ptr()), ws.numel(),
-            C.c_void_p(met.data_ptr()) if met is not None else None, C.c_void_p(rs.data_ptr()),
+            C.c_void_p(met.data_ptr()) if met is not None else None, C.c_void_p(rs.data_ptr()) if rs is not None else None,
             C.c_void_p(ss.data_ptr()) if ss is not None else None, self._stream()))
-        self._last = (frames, L, n_steps)
         return met, rs
 
     def chainback(self, frames: int, L: int, end_state=None, out=None):
@@ -293,7 +296,6 @@ class BatchDecoder:
             self._handle._h, C.c_void_p(symbols.data_ptr()), frames, L, C.c_void_p(ws.data_ptr()), ws.numel(),
             C.c_void_p(out.data_ptr()), C.c_void_p(met.data_ptr()) if met is not None else None,
             C.c_void_p(rs.data_ptr()) if rs is not None else None, None, self._stream()))
-        self._last = (frames, L, L + self.K - 1)
         return (out, met, rs) if want_metrics else out
 
     def export_decisions(self, frames: int, L: int, n_steps: int = None):
