@@ -21,14 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace vit {
+#include "common.hpp"
 
-// Decoder constants in the device's 16-bit domain: every value is (reference value << shift), shift = 0 for
-// (int16_t,uint16_t) and 8 for (int8_t,uint8_t).
-struct DevConfig {
-    uint16_t max_error, init_start, init_non_start, threshold;
-    int16_t high, low;
-};
+namespace vit {
 
 struct LdsUpdateArgs {
     const uint8_t* symbols;          // device, raw bytes of [F][n_steps][R] soft_t

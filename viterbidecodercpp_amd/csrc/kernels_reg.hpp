@@ -34,7 +34,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "kernels_lds.hpp"
+#include "common.hpp"
 
 namespace vit {
 
@@ -61,6 +61,12 @@ VIT_DEV u32 pk_max_s(u32 a, u32 b) {
 VIT_DEV u32 pk_sub_sat(u32 a, u32 b) {
     u32 d;
     asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// per-half min(x, 1): 0/1 decision bits.  Inline asm for the same reason (umin(x,1) -> zext(x != 0) -> cmp+cndmask+perm).
+VIT_DEV u32 pk_bit(u32 s) {
+    u32 d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(s), "s"(0x00010001u));
     return d;
 }
 // d = lanemask[lane] ? b : a, lanemask a wave-uniform 64-bit constant
@@ -150,17 +156,22 @@ struct RegUpdateArgs {
     DevConfig cfg;
 };
 
-// 16 bytes of a frame's symbol stream; never reads at or beyond `end`
-VIT_DEV uint4 load_chunk(const uint8_t* base, size_t off, size_t end) {
-    if (off + 16 <= end) {
-        uint4 v;
-        __builtin_memcpy(&v, base + off, 16);
-        return v;
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+// 16 bytes of a frame's symbol stream through a bounds-checked buffer descriptor: bytes at or beyond the end of the
+// caller's buffer read as zero in hardware (no branches, no over-read).  `voff` is dword aligned; when a frame does not
+// start on a dword (odd strides: R = 3 with 8-bit symbols) `fix` is set wave-wide and the 16 bytes are funnel-shifted
+// out of 20 with v_alignbyte.
+VIT_DEV uint4 load_chunk(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 mis, bool fix) {
+    const v4i32_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    uint4 r = make_uint4((u32)v.x, (u32)v.y, (u32)v.z, (u32)v.w);
+    if (fix) {
+        const u32 e = (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff + 16, 0, 0);
+        r.x = __builtin_amdgcn_alignbyte(r.y, r.x, mis);
+        r.y = __builtin_amdgcn_alignbyte(r.z, r.y, mis);
+        r.z = __builtin_amdgcn_alignbyte(r.w, r.z, mis);
+        r.w = __builtin_amdgcn_alignbyte(e, r.w, mis);
     }
-    u32 w[4] = {0, 0, 0, 0};
-    for (int k = 0; k < 16; ++k)
-        if (off + k < end) w[k >> 2] |= (u32)base[off + k] << ((k & 3) * 8);
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return r;
 }
 
 template <class SP, int SHIFT>
@@ -179,7 +190,19 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
     const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
     const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
-    const size_t offA = (size_t)fA * a.sym_frame_stride_bytes, offB = (size_t)fB * a.sym_frame_stride_bytes;
+    // descriptor over [first frame of this tile (rounded down to a dword), end of the symbol buffer): wave-uniform base,
+    // 32-bit per-lane offsets
+    const size_t tile_off = tile * 32 * a.sym_frame_stride_bytes;
+    const u32 bmis = (u32)(((uintptr_t)a.symbols + tile_off) & 3u);
+    // rounded up to whole dwords: the range check is per dword, and the dword holding the buffer's last bytes must not
+    // be dropped (it cannot straddle an allocation granule)
+    const size_t remain = (a.sym_total_bytes - tile_off + bmis + 3) & ~(size_t)3;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.symbols + tile_off - bmis), 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain, 0x00020000);
+    const u32 rawA = (fA - (u32)tile * 32) * (u32)a.sym_frame_stride_bytes + bmis;
+    const u32 rawB = (fB - (u32)tile * 32) * (u32)a.sym_frame_stride_bytes + bmis;
+    const u32 offA = rawA & ~3u, offB = rawB & ~3u, misA = rawA & 3u, misB = rawB & 3u;
+    const bool fix = __builtin_amdgcn_ballot_w64((misA | misB) != 0) != 0;   // wave-uniform
 
     const u32 HIGH2 = (u32)(uint16_t)a.cfg.high * 0x10001u, LOW2 = (u32)(uint16_t)a.cfg.low * 0x10001u;
     const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u, THR2 = (u32)a.cfg.threshold * 0x10001u;
@@ -201,8 +224,8 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     uint4 cA[NCH], cB[NCH];
     static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        cA[c] = load_chunk(a.symbols, offA + 16 * c, a.sym_total_bytes);
-        cB[c] = load_chunk(a.symbols, offB + 16 * c, a.sym_total_bytes);
+        cA[c] = load_chunk(rsrc, offA + 16 * c, misA, fix);
+        cB[c] = load_chunk(rsrc, offB + 16 * c, misB, fix);
     });
 
     uint64_t rsA = 0, rsB = 0;
@@ -284,7 +307,7 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                     const u32 s0 = pk_sub_sat(x0, y0), s1 = pk_sub_sat(x1, y1);
                     m[r0] = pk_sub(x0, s0);
                     m[r1] = pk_sub(x1, s1);
-                    const u32 b0 = pk_min_u(s0, 0x00010001u), b1 = pk_min_u(s1, 0x00010001u);
+                    const u32 b0 = pk_bit(s0), b1 = pk_bit(s1);
                     if constexpr (LP && NREG == 16) {
                         acc[0] |= b0 << r0;      // r0 < 8: slots with register bit T == (this lane's bit), lane bit 0
                         acc_hi |= b1 << r0;      // same positions, slot lane bit 1
@@ -348,9 +371,9 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                     constexpr int first_use = (16 * c) / BPS;
                     if constexpr (last_use == u) {
                         if (t0 + U + first_use < a.n_steps) {
-                            const size_t o = (size_t)(t0 + U) * BPS + 16 * c;
-                            cA[c] = load_chunk(a.symbols, offA + o, a.sym_total_bytes);
-                            cB[c] = load_chunk(a.symbols, offB + o, a.sym_total_bytes);
+                            const u32 o = (t0 + U) * BPS + 16 * c;
+                            cA[c] = load_chunk(rsrc, offA + o, misA, fix);
+                            cB[c] = load_chunk(rsrc, offB + o, misB, fix);
                         }
                     }
                 });
@@ -547,12 +570,52 @@ inline size_t reg_workspace_bytes(const RegCode& rc, size_t frames, size_t L) {
     return reg_tiles(frames) * reg_groups(rc, L) * 1024;
 }
 
-template <class SP>
-int reg_update_launch(int shift, const RegUpdateArgs& a, size_t tiles, hipStream_t st) {
-    if (shift) hipLaunchKernelGGL((reg_update_kernel<SP, 8>), dim3((unsigned)tiles), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((reg_update_kernel<SP, 0>), dim3((unsigned)tiles), dim3(64), 0, st, a);
+// The kernels are instantiated one code per translation unit (reg_inst.hip, compiled with -DVIT_REG_ID=0..4) so that the
+// heavy unrolled bodies build in parallel; these are the per-code launchers those units define.
+template <int ID> struct RegSpecOf;
+template <> struct RegSpecOf<0> { using type = Spec_K7R2; };
+template <> struct RegSpecOf<1> { using type = Spec_K7R3; };
+template <> struct RegSpecOf<2> { using type = Spec_K7R4; };
+template <> struct RegSpecOf<3> { using type = Spec_K9R2; };
+template <> struct RegSpecOf<4> { using type = Spec_K9R4; };
+
+template <int ID> int reg_launch_update(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st);
+template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st);
+template <int ID> int reg_launch_export(const RegExportArgs& a, unsigned blocks, hipStream_t st);
+
+#ifdef VIT_REG_ID
+template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st) {
+    using SP = RegSpecOf<VIT_REG_ID>::type;
+    if (shift) hipLaunchKernelGGL((reg_update_kernel<SP, 8>), dim3(tiles), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((reg_update_kernel<SP, 0>), dim3(tiles), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
+    using SP = RegSpecOf<VIT_REG_ID>::type;
+    hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
+    using SP = RegSpecOf<VIT_REG_ID>::type;
+    hipLaunchKernelGGL(reg_export_kernel<SP>, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#else
+template <> int reg_launch_update<0>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<1>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<2>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<3>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<4>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<0>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<1>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<2>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<3>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<4>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<0>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<1>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<2>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<3>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<4>(const RegExportArgs&, unsigned, hipStream_t);
 
 inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t frames,
                       size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start,
@@ -561,6 +624,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     RegUpdateArgs a{};
     a.symbols = (const uint8_t*)d_symbols;
     a.sym_frame_stride_bytes = n_steps * (size_t)rc.R * (shift ? 1 : 2);
+    if (a.sym_frame_stride_bytes * 32 >= 0xFFFFFFFFull) return -2;   // per-lane 32-bit buffer offsets
     a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
     a.ws = (uint4*)d_ws;
     a.ws_tile_stride = reg_groups(rc, L) * 64;
@@ -570,13 +634,13 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     a.frames = (u32)frames;
     a.n_steps = (u32)n_steps;
     a.cfg = cfg;
-    const size_t tiles = reg_tiles(frames);
+    const unsigned tiles = (unsigned)reg_tiles(frames);
     switch (rc.id) {
-        case 0: return reg_update_launch<Spec_K7R2>(shift, a, tiles, st);
-        case 1: return reg_update_launch<Spec_K7R3>(shift, a, tiles, st);
-        case 2: return reg_update_launch<Spec_K7R4>(shift, a, tiles, st);
-        case 3: return reg_update_launch<Spec_K9R2>(shift, a, tiles, st);
-        case 4: return reg_update_launch<Spec_K9R4>(shift, a, tiles, st);
+        case 0: return reg_launch_update<0>(shift, a, tiles, st);
+        case 1: return reg_launch_update<1>(shift, a, tiles, st);
+        case 2: return reg_launch_update<2>(shift, a, tiles, st);
+        case 3: return reg_launch_update<3>(shift, a, tiles, st);
+        case 4: return reg_launch_update<4>(shift, a, tiles, st);
         default: return -1;
     }
 }
@@ -593,14 +657,13 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.L = (u32)L;
     const unsigned tiles = (unsigned)reg_tiles(frames);
     switch (rc.id) {
-        case 0: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R2>, dim3(tiles), dim3(64), 0, st, a); break;
-        case 1: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R3>, dim3(tiles), dim3(64), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K7R4>, dim3(tiles), dim3(64), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K9R2>, dim3(tiles), dim3(64), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(reg_chainback_kernel<Spec_K9R4>, dim3(tiles), dim3(64), 0, st, a); break;
+        case 0: return reg_launch_chainback<0>(a, tiles, st);
+        case 1: return reg_launch_chainback<1>(a, tiles, st);
+        case 2: return reg_launch_chainback<2>(a, tiles, st);
+        case 3: return reg_launch_chainback<3>(a, tiles, st);
+        case 4: return reg_launch_chainback<4>(a, tiles, st);
         default: return -1;
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t n_steps, size_t L, uint64_t* d_out,
@@ -615,9 +678,8 @@ inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t
     const size_t W = rc.K == 9 ? 4 : 1;
     const size_t total = frames * n_steps * W;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (rc.K == 9) hipLaunchKernelGGL(reg_export_kernel<Spec_K9R2>, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(reg_export_kernel<Spec_K7R2>, dim3(blocks), dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return rc.K == 9 ? reg_launch_export<3>(a, blocks, st) : reg_launch_export<0>(a, blocks, st);
 }
+#endif  // VIT_REG_ID
 
 }  // namespace vit
