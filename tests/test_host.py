@@ -1,0 +1,102 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol include/vit_hip.h declares,
+argument checking happens before any device is touched, the host mirror of the reference interface builds the same branch
+table as the reference, and there is NO CPU decode path (no GPU => loud failure)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from viterbidecodercpp_amd import (COMMON_CODES, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core, _lib,
+                                   get_decoding_config, pack_blob, synth)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vit_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(vit_hip_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_branch_table_matches_reference_fixture():
+    manifest = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
+    for name, meta in manifest.items():
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        pc = get_decoding_config(meta["decode_type"], meta["R"])
+        t = ViterbiBranchTable(meta["K"], meta["R"], meta["G"], pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+        assert np.array_equal(t.data().astype(np.int16), g["table"]), name
+        assert np.array_equal(t[0], t.data()[0])
+
+
+def test_blob_round_trip_layout():
+    code = COMMON_CODES[2]
+    pc = get_decoding_config("SOFT16", code.R)
+    t = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    cfg = ViterbiDecoder_Config.from_decoder_config(pc)
+    blob = pack_blob(t, cfg)
+    lib = _lib.load()
+    assert len(blob) == lib.vit_hip_blob_bytes(7, 2, 2, 2) == 20 + 2 * 32 * 2 + 8
+    assert blob[20:20 + 128] == t.data().tobytes()
+    assert blob[-8:] == cfg.as_array().tobytes()
+
+
+def test_argument_errors_come_before_device_access():
+    lib = _lib.load()
+    h = C.c_void_p()
+    tbl = np.zeros((2, 32), dtype=np.int16)
+    cfg = np.zeros(4, dtype=np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert lib.vit_hip_create(1, 2, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_create(16, 2, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_create(7, 9, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_create(7, 2, 2, 1, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_create(7, 2, 2, 2, None, p(cfg), 0, C.byref(h)) == _lib.ERR_INVALID_ARG
+    assert b"NULL" in lib.vit_hip_last_error()
+    assert lib.vit_hip_update_batch(None, None, 1, 1, 1, None, 0, None, None, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_create_from_blob(p(np.zeros(4, np.uint8)), 4, 0, C.byref(h)) == _lib.ERR_INVALID_ARG
+
+
+def test_no_cpu_fallback_without_gpu():
+    """on a machine without a GPU the product path must fail loudly, never decode on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    code = COMMON_CODES[2]
+    pc = get_decoding_config("SOFT16", code.R)
+    t = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    with pytest.raises(_lib.VitHipError) as e:
+        ViterbiDecoder_Core(t, ViterbiDecoder_Config.from_decoder_config(pc))
+    assert e.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "viterbidecodercpp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "pyoracle" not in src and "viterbi_oracle" not in src and "libvitref" not in src, fn
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        pass
+
+
+def test_synth_numpy_and_torch_encoders_agree():
+    import torch
+
+    code = COMMON_CODES[5]
+    pc = get_decoding_config("SOFT16", code.R)
+    tx, sym = synth.make_frames_torch(code, pc, 5, 256, None, seed=3, device="cpu")
+    coded = synth.encode_bits_numpy(code.K, code.R, code.G, tx.numpy())
+    want = np.where(coded != 0, pc.soft_decision_high, pc.soft_decision_low).astype(np.int16)
+    assert np.array_equal(sym.numpy(), want)
+    # noisy symbols stay inside the soft-decision range
+    _, noisy = synth.make_frames_torch(code, pc, 3, 256, 1.0, seed=4, device="cpu")
+    assert int(noisy.max()) <= pc.soft_decision_high and int(noisy.min()) >= pc.soft_decision_low

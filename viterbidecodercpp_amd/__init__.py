@@ -6,7 +6,7 @@ interface in decoder.py.  codes.py / synth.py hold constants and synthetic-input
 from .codes import COMMON_CODES, Code, DecoderConfig, get_decoding_config, SOFT16, SOFT8, HARD8  # noqa: F401
 from .decoder import (BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core,  # noqa: F401
                       ViterbiDecoder_HIP, pack_blob)
-from . import _lib  # noqa: F401
+from . import _lib, dist, synth  # noqa: F401
 
 __all__ = ["COMMON_CODES", "Code", "DecoderConfig", "get_decoding_config", "SOFT16", "SOFT8", "HARD8", "BatchDecoder",
            "ViterbiBranchTable", "ViterbiDecoder_Config", "ViterbiDecoder_Core", "ViterbiDecoder_HIP", "pack_blob"]
