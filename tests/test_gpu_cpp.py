@@ -1,0 +1,41 @@
+"""The C++ host layer (include/viterbi_hip/*.h) exercised by C++ programs that mirror the reference's own executables:
+run_simple (examples/run_simple.cpp) and the run_tests matrix (examples/run_tests.cpp), the latter extended with noisy
+frames checked bit for bit against the oracle.  Built by __graft_entry__.build() / `make -C tests/cpp`."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _ensure_built():
+    if not (os.path.exists(os.path.join(CPP, "run_simple_hip")) and os.path.exists(os.path.join(CPP, "run_tests_hip"))):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
+
+
+def test_cpp_programs_build():
+    _ensure_built()
+    subprocess.run(["make", "-q", "-C", CPP], check=False)
+    assert os.access(os.path.join(CPP, "run_simple_hip"), os.X_OK)
+    assert os.access(os.path.join(CPP, "run_tests_hip"), os.X_OK)
+
+
+@pytest.mark.gpu
+def test_run_simple_hip():
+    _ensure_built()
+    p = subprocess.run([os.path.join(CPP, "run_simple_hip")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "error_metric=0" in p.stdout and "0/8192 incorrect bits" in p.stdout
+
+
+@pytest.mark.gpu
+def test_run_tests_hip_matrix():
+    _ensure_built()
+    p = subprocess.run([os.path.join(CPP, "run_tests_hip")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr
+    assert "FAIL" not in p.stdout
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith("PASSED ") and last.split()[1].split("/")[0] == last.split()[1].split("/")[1]
