@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (scripts/profile.sh) into profiles/<tag>_summary.md + profiles/<tag>_kernel_stats.csv and
+update profiles/traffic.json (read by bench.py for roofline.traffic).
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KiB (x1024); on gfx950
+FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced streaming reads, so the read side is doubled
+("corrected"); WRITE_SIZE is exact for 16-byte-per-lane stores.  Both the raw and corrected numbers are printed.
+usage: summarize_profile.py <tag> [<traffic-key>]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+key = sys.argv[2] if len(sys.argv) > 2 else None
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+KERNELS = ("reg_update_kernel", "reg_chainback_kernel", "reg_export_kernel", "lds_update_kernel", "lds_chainback_kernel")
+
+
+def short(name):
+    name = name.replace("void ", "")
+    for k in KERNELS:
+        if k in name:
+            return "vit::" + k + name.split(k, 1)[1].split("(")[0]
+    return name.split("(")[0][:60]
+
+
+lines = [f"# rocprofv3 summary `{tag}`", "",
+         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+         "(scripts/profile.sh; the 2 warm-up launches are included in the averages).", ""]
+
+# ---- pass 1: kernel stats ----
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]
+        w.writerow(cols)
+        for r in rows:
+            w.writerow([r[c] for c in cols])
+    lines += ["## --kernel-trace --stats (vit:: kernels)", "", "| kernel | calls | avg ms | min ms | max ms | % of GPU time |",
+              "|---|---|---|---|---|---|"]
+    for r in rows:
+        if "vit::" in r["Name"]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['MinNs'])/1e6:.3f} | "
+                         f"{float(r['MaxNs'])/1e6:.3f} | {r['Percentage']} |")
+    lines.append("")
+
+# ---- PMC passes ----
+counters = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values per dispatch]
+meta = {}
+for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(path)):
+        if "vit::" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = dict(vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"],
+                       scratch=r["Scratch_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"])
+
+traffic = {}
+for k in sorted(counters):
+    c = {n: sum(v) / len(v) for n, v in counters[k].items()}
+    m = meta[k]
+    lines += [f"## PMC, per launch: `{k}`", "",
+              f"grid {m['grid']} threads, workgroup {m['wg']}, VGPR {m['vgpr']} (+{m['agpr']} acc), SGPR {m['sgpr']}, "
+              f"LDS {m['lds']} B, scratch {m['scratch']} B", "", "| counter | value per launch |", "|---|---|"]
+    for n in sorted(c):
+        lines.append(f"| {n} | {c[n]:.6g} |")
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        rd_raw, wr = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+        rd = 2 * rd_raw
+        lines += ["", f"HBM read  : FETCH_SIZE x 1024 = {rd_raw/1e9:.3f} GB raw, x2 gfx950 correction = **{rd/1e9:.3f} GB**",
+                  f"HBM write : WRITE_SIZE x 1024 = **{wr/1e9:.3f} GB**",
+                  f"HBM total (corrected) = **{(rd+wr)/1e9:.3f} GB** per launch"]
+        traffic[k] = dict(read_raw=rd_raw, read_corrected=rd, write=wr, total=rd + wr)
+    if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
+        lines.append(f"VALU instructions per wave = {c['SQ_INSTS_VALU']/c['SQ_WAVES']:.0f}; "
+                     f"SALU per wave = {c.get('SQ_INSTS_SALU', 0)/c['SQ_WAVES']:.0f}")
+    if "SQ_LDS_BANK_CONFLICT" in c:
+        act = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        lines.append(f"LDS bank-conflict cycles / LDS active cycles = {c['SQ_LDS_BANK_CONFLICT']:.6g} / {act:.6g}"
+                     + (f" = {c['SQ_LDS_BANK_CONFLICT']/act:.3%}" if act else ""))
+    if "TCC_HIT_sum" in c:
+        tot = c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0)
+        if tot:
+            lines.append(f"L2 hit rate = {c['TCC_HIT_sum']/tot:.3%}")
+    lines.append("")
+
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+
+if key and traffic:
+    tpath = os.path.join(dst, "traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    upd = [k for k in traffic if "update_kernel" in k]
+    cb = [k for k in traffic if "chainback_kernel" in k]
+    tj[key] = {"source": f"profiles/{tag}_summary.md",
+               "update_kernel_hbm_bytes_per_launch": traffic[upd[0]]["total"] if upd else None,
+               "chainback_kernel_hbm_bytes_per_launch": traffic[cb[0]]["total"] if cb else None,
+               "detail": traffic}
+    json.dump(tj, open(tpath, "w"), indent=1)
