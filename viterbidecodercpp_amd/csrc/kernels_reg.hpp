@@ -63,10 +63,13 @@ VIT_DEV u32 pk_sub_sat(u32 a, u32 b) {
     asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-// per-half min(x, 1): 0/1 decision bits.  Inline asm for the same reason (umin(x,1) -> zext(x != 0) -> cmp+cndmask+perm).
-VIT_DEV u32 pk_bit(u32 s) {
+VIT_DEV u32 pk_min_s(u32 a, u32 b) {
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+// per-half SIGNED saturating subtract: the sign bit of each half is exactly (a < b) as signed 16-bit, whatever the distance
+VIT_DEV u32 pk_sub_sat_s(u32 a, u32 b) {
     u32 d;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(s), "s"(0x00010001u));
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 // d = lanemask[lane] ? b : a, lanemask a wave-uniform 64-bit constant
@@ -115,6 +118,9 @@ struct RegSpec {
         for (int i = 0; i < R; ++i) p |= parity((v << 1) & G(i)) << i;
         return p;
     }
+    // position of the decision bit of slot register r (frame half h) inside its decision dword r/16: the sign bits of
+    // register pairs (2k, 2k+1) are byte-gathered, so even registers land in bytes 0/1 (frame A/B), odd ones in bytes 2/3
+    static constexpr u32 dec_bit(u32 r, u32 h) { return ((r & 15u) >> 1) + 8u * h + 16u * (r & 1u); }
     // slot bit exchanged by the butterflies of phase ph, and whether that is a lane bit
     static constexpr int pbit(int ph) { return SB - 1 - ph; }
     static constexpr bool lane_phase(int ph) { return pbit(ph) >= REG_BITS; }
@@ -183,6 +189,7 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     constexpr int U = clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
     constexpr int NCH = U * BPS / 16;
     constexpr int NP = 1 << R;
+    constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
     const int lane = threadIdx.x & 63;
     const u32 g = lane & 15, q = lane >> 4;
@@ -190,6 +197,7 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
     const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
     const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
+
     // descriptor over [first frame of this tile (rounded down to a dword), end of the symbol buffer): wave-uniform base,
     // 32-bit per-lane offsets
     const size_t tile_off = tile * 32 * a.sym_frame_stride_bytes;
@@ -205,7 +213,25 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     const bool fix = __builtin_amdgcn_ballot_w64((misA | misB) != 0) != 0;   // wave-uniform
 
     const u32 HIGH2 = (u32)(uint16_t)a.cfg.high * 0x10001u, LOW2 = (u32)(uint16_t)a.cfg.low * 0x10001u;
-    const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u, THR2 = (u32)a.cfg.threshold * 0x10001u;
+    const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u;
+    // new_metric[0] >= threshold  <=>  biased metric > biased (threshold - 1); threshold == 0 means "always"
+    const u32 THRM1B2 = ((u32)(uint16_t)(a.cfg.threshold - 1) * 0x10001u) ^ BIAS2;
+    const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
+    const u32 MASKQ = q == 0 ? BIAS2 : 0u;   // state 0 is slot 0: lane group q == 0, register 0
+
+    // the branch pattern contributed by this lane's group q is folded in by exchanging `high` and `low` per polynomial:
+    // per-lane constants, one pair per (phase, polynomial)
+    u32 HIc[SB][R], LOc[SB][R];
+    static_for<SB>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int ph = decltype(pc)::value;
+        static_for<R>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr uint64_t LM = SP::lane_mask(ph, i);
+            const bool swapped = (LM >> lane) & 1ull;
+            HIc[ph][i] = swapped ? LOW2 : HIGH2;
+            LOc[ph][i] = swapped ? HIGH2 : LOW2;
+        });
+    });
 
     // ---- reset (viterbi_decoder_core.h:202-211): phase 0, slot == state ----
     u32 m[NREG];
@@ -217,7 +243,7 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
             const u32 x = (q << REG_BITS) | r;
             const u32 lo = (x == sA) ? a.cfg.init_start : a.cfg.init_non_start;
             const u32 hi = (x == sB) ? a.cfg.init_start : a.cfg.init_non_start;
-            m[r] = lo | (hi << 16);
+            m[r] = (lo | (hi << 16)) ^ BIAS2;
         });
     }
 
@@ -232,45 +258,68 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     u32 dq[4] = {0, 0, 0, 0};
     uint4* ws_tile = a.ws + tile * a.ws_tile_stride;
 
-    for (u32 t0 = 0; t0 < a.n_steps; t0 += U) {
+    // E[p] = sum_i |bt_i - y_i| for every branch pattern p and EB[p] = max_error - E[p]  (scalar.h:66-73,107) of block
+    // step `un` (un == U: step 0 of the NEXT block, whose chunks are already refilled).  Depends on symbols only, so it is
+    // computed one step AHEAD, inside the basic block of the previous step's add-compare-select: its dependent chain
+    // (perm -> sub -> neg -> max -> add -> sub) then overlaps ACS work instead of stalling the start of every step.
+    u32 E[2][NP], EB[2][NP];
+    auto branch_metrics = [&](auto unc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value;
+        constexpr int us = un % U;            // position inside the (current or next) block
+        constexpr int PHn = us % SB;
+        constexpr int buf = un & 1;
+        u32 A1[R], A0[R];
+        static_for<R>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int o = us * BPS + i * SBY;
+            constexpr int c = o / 16, d = (o % 16) / 4, sub = o % 4;
+            const u32 wa = d == 0 ? cA[c].x : d == 1 ? cA[c].y : d == 2 ? cA[c].z : cA[c].w;
+            const u32 wb = d == 0 ? cB[c].x : d == 1 ? cB[c].y : d == 2 ? cB[c].z : cB[c].w;
+            constexpr u32 sel = SHIFT ? (0x0cu | ((u32)sub << 8) | (0x0cu << 16) | ((u32)(4 + sub) << 24))
+                                      : ((u32)sub | ((u32)(sub + 1) << 8) | ((u32)(4 + sub) << 16) | ((u32)(5 + sub) << 24));
+            const u32 Y = __builtin_amdgcn_perm(wb, wa, sel);   // (frame A | frame B << 16) in the device's 16-bit domain
+            // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71) for expected = high and = low
+            const u32 d1 = pk_sub(HIc[PHn][i], Y), d0 = pk_sub(LOc[PHn][i], Y);
+            A1[i] = pk_max_s(d1, pk_sub(0u, d1));
+            A0[i] = pk_max_s(d0, pk_sub(0u, d0));
+        });
+        static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            u32 e = (p & 1) ? A1[0] : A0[0];
+            static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value + 1;
+                e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
+            });
+            E[buf][p] = e;
+            EB[buf][p] = pk_sub(MAXE2, e);
+        });
+    };
+    static_assert(U % 2 == 0, "E double buffer alternates per step");
+    branch_metrics(std::integral_constant<int, 0>{});
+
+    u32 t0 = 0;
+    // one unrolled block of U trellis steps; `guarded` adds the per-step bound check needed only by the last, partial block
+    auto block = [&](auto guarded_c) __attribute__((always_inline)) {
+        constexpr bool GUARDED = decltype(guarded_c)::value;
         static_for<U>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
             constexpr int PH = u % SB;
-            if (t0 + u < a.n_steps) {
-                // ---- symbols of this step, packed (frame A | frame B << 16), in the device's 16-bit domain ----
-                u32 A1[R], A0[R];
-                static_for<R>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    constexpr int o = u * BPS + i * SBY;
-                    constexpr int c = o / 16, d = (o % 16) / 4, sub = o % 4;
-                    const u32 wa = d == 0 ? cA[c].x : d == 1 ? cA[c].y : d == 2 ? cA[c].z : cA[c].w;
-                    const u32 wb = d == 0 ? cB[c].x : d == 1 ? cB[c].y : d == 2 ? cB[c].z : cB[c].w;
-                    constexpr u32 sel = SHIFT ? (0x0cu | ((u32)sub << 8) | (0x0cu << 16) | ((u32)(4 + sub) << 24))
-                                              : ((u32)sub | ((u32)(sub + 1) << 8) | ((u32)(4 + sub) << 16) | ((u32)(5 + sub) << 24));
-                    const u32 Y = __builtin_amdgcn_perm(wb, wa, sel);
-                    // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71) for expected = high and = low
-                    const u32 d1 = pk_sub(HIGH2, Y), d0 = pk_sub(LOW2, Y);
-                    u32 a1 = pk_max_s(d1, pk_sub(0u, d1)), a0 = pk_max_s(d0, pk_sub(0u, d0));
-                    constexpr uint64_t LM = SP::lane_mask(PH, i);
-                    if constexpr (LM == ~0ull) {
-                        const u32 tmp = a1; a1 = a0; a0 = tmp;
-                    } else if constexpr (LM != 0) {
-                        const u32 t1 = cnd_mask(a1, a0, LM), t0_ = cnd_mask(a0, a1, LM);
-                        a1 = t1; a0 = t0_;
+            constexpr int cur = u & 1;
+            if (!GUARDED || t0 + u < a.n_steps) {
+                branch_metrics(std::integral_constant<int, u + 1>{});
+                // ---- refill the symbol chunks whose last reader was that look-ahead (next needed ~U steps from now) ----
+                static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    constexpr int last_use = (16 * c + 15) / BPS;          // step of this block that reads byte 16c+15
+                    constexpr int first_use = (16 * c) / BPS;
+                    static_assert(last_use >= 1, "a 16-byte chunk spans at least two steps");
+                    if constexpr (last_use - 1 == u) {
+                        if (t0 + U + first_use < a.n_steps) {
+                            const u32 o = (t0 + U) * BPS + 16 * c;
+                            cA[c] = load_chunk(rsrc, offA + o, misA, fix);
+                            cB[c] = load_chunk(rsrc, offB + o, misB, fix);
+                        }
                     }
-                    A1[i] = a1; A0[i] = a0;
-                });
-                // ---- E[p] = sum_i |bt_i - y_i| for every branch pattern p, and max_error - E[p]  (scalar.h:66-73,107) ----
-                u32 E[NP], EB[NP];
-                static_for<NP>([&](auto pc) __attribute__((always_inline)) {
-                    constexpr int p = decltype(pc)::value;
-                    u32 e = (p & 1) ? A1[0] : A0[0];
-                    static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value + 1;
-                        e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
-                    });
-                    E[p] = e;
-                    EB[p] = pk_sub(MAXE2, e);
                 });
 
                 constexpr bool LP = SP::lane_phase(PH);
@@ -292,9 +341,8 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                     });
                 }
                 // ---- add-compare-select, in place  (scalar.h:113-134) ----
-                u32 acc[DW];
-                u32 acc_hi = 0;  // NREG == 16 lane phases only
-                static_for<DW>([&](auto dc) __attribute__((always_inline)) { acc[decltype(dc)::value] = 0; });
+                // biased metrics: x > y (unsigned, reference)  <=>  sign of sat_i16(y' - x'); min is the signed min
+                u32 D[NREG];
                 static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
                     constexpr int h = decltype(hc)::value;
                     // h enumerates the NREG/2 register indices with bit PB clear
@@ -302,34 +350,44 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                     constexpr int r1 = r0 | (1 << PB);
                     constexpr u32 p = SP::pat_reg(PH, (u32)r0);
                     const u32 ma = m[r0], mb = m[r1];
-                    const u32 x0 = pk_add(ma, E[p]), y0 = pk_add(mb, EB[p]);   // -> next state (X|0)
-                    const u32 x1 = pk_add(ma, EB[p]), y1 = pk_add(mb, E[p]);   // -> next state (X|1)
-                    const u32 s0 = pk_sub_sat(x0, y0), s1 = pk_sub_sat(x1, y1);
-                    m[r0] = pk_sub(x0, s0);
-                    m[r1] = pk_sub(x1, s1);
-                    const u32 b0 = pk_bit(s0), b1 = pk_bit(s1);
-                    if constexpr (LP && NREG == 16) {
-                        acc[0] |= b0 << r0;      // r0 < 8: slots with register bit T == (this lane's bit), lane bit 0
-                        acc_hi |= b1 << r0;      // same positions, slot lane bit 1
-                    } else {
-                        acc[r0 / 16] |= b0 << (r0 % 16);
-                        acc[r1 / 16] |= b1 << (r1 % 16);
-                    }
+                    const u32 x0 = pk_add(ma, E[cur][p]), y0 = pk_add(mb, EB[cur][p]);   // -> next state (X|0)
+                    const u32 x1 = pk_add(ma, EB[cur][p]), y1 = pk_add(mb, E[cur][p]);   // -> next state (X|1)
+                    m[r0] = pk_min_s(x0, y0);
+                    m[r1] = pk_min_s(x1, y1);
+                    D[r0] = pk_sub_sat_s(y0, x0);   // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
+                    D[r1] = pk_sub_sat_s(y1, x1);
                 });
+                // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
+                const u32 need = (pk_sub_sat_s(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
+                // ---- gather the 2 x NREG sign bits: bytes 1 and 3 of a register pair -> one dword, 8 pairs per dword ----
+                constexpr u32 SIGNS = 0x80808080u;
+                constexpr u32 HI_BYTES = 0x07050301u;   // {D[r].b1, D[r].b3, D[r+1].b1, D[r+1].b3}
+                u32 acc[DW];
+                static_for<DW>([&](auto dc) __attribute__((always_inline)) {
+                    constexpr int d = decltype(dc)::value;
+                    // two independent 4-deep chains instead of one 8-deep: pair k ends at bit k of each byte
+                    u32 lo4 = 0, hi4 = 0;
+                    static_for<4>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        constexpr int r = 16 * d + 2 * k;
+                        lo4 = (__builtin_amdgcn_perm(D[r + 1], D[r], HI_BYTES) & SIGNS) | (lo4 >> 1);
+                        hi4 = (__builtin_amdgcn_perm(D[r + 9], D[r + 8], HI_BYTES) & SIGNS) | (hi4 >> 1);
+                    });
+                    // NREG == 16 in a lane phase: registers 0-7 / 8-15 belong to different lanes until the exchange is undone
+                    if constexpr (LP && NREG == 16) lane_swap(lo4, hi4);
+                    acc[d] = (lo4 >> 4) | hi4;
+                });
+                if constexpr (LP && NREG > 16) {
+                    static_for<DW / 2>([&](auto dc) __attribute__((always_inline)) {
+                        constexpr int d = decltype(dc)::value;
+                        lane_swap(acc[d], acc[d + DW / 2]);
+                    });
+                }
                 if constexpr (LP) {
                     static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
                         constexpr int r0 = decltype(hc)::value;
                         lane_swap(m[r0], m[r0 | (1 << T)]);
                     });
-                    if constexpr (NREG == 16) {
-                        lane_swap(acc[0], acc_hi);
-                        acc[0] |= acc_hi << (1 << T);
-                    } else {
-                        static_for<DW / 2>([&](auto dc) __attribute__((always_inline)) {
-                            constexpr int d = decltype(dc)::value;
-                            lane_swap(acc[d], acc[d + DW / 2]);
-                        });
-                    }
                 }
                 // ---- decision rows: 16 bytes per lane, 1 KiB per wave, coalesced ----
                 if constexpr (DW == 4) {
@@ -344,18 +402,17 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                 }
                 // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153); state 0 is slot 0 ----
                 {
-                    const u32 z = pk_sub_sat(THR2, m[0]);  // half == 0  <=>  metric >= threshold
-                    const bool need = (q == 0) && (((z & 0xFFFFu) == 0) || ((z >> 16) == 0));
-                    if (__builtin_amdgcn_ballot_w64(need) != 0) {
-                        const u32 zq = (u32)__shfl((int)z, (int)g);
-                        const u32 msk = (((zq & 0xFFFFu) == 0) ? 0x0000FFFFu : 0u) | (((zq >> 16) == 0) ? 0xFFFF0000u : 0u);
+                    const u32 need2 = LP ? ((pk_sub_sat_s(THRM1B2, m[0]) | FORCE) & MASKQ) : need;
+                    if (__builtin_amdgcn_ballot_w64(need2 != 0) != 0) {
+                        const u32 nq = (u32)__shfl((int)need2, (int)g);
+                        const u32 msk = ((nq & 0x8000u) ? 0x0000FFFFu : 0u) | ((nq & 0x80000000u) ? 0xFFFF0000u : 0u);
                         u32 mn = m[0];
                         static_for<NREG - 1>([&](auto rc) __attribute__((always_inline)) {
-                            mn = pk_min_u(mn, m[decltype(rc)::value + 1]);
+                            mn = pk_min_s(mn, m[decltype(rc)::value + 1]);
                         });
-                        mn = pk_min_u(mn, (u32)__shfl_xor((int)mn, 16));
-                        mn = pk_min_u(mn, (u32)__shfl_xor((int)mn, 32));
-                        const u32 sub = mn & msk;
+                        mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 16));
+                        mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 32));
+                        const u32 sub = (mn ^ BIAS2) & msk;   // the true (unbiased) minimum of each frame that renormalises
                         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
                             constexpr int r = decltype(rc)::value;
                             m[r] = pk_sub(m[r], sub);
@@ -364,22 +421,12 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                         rsB += (uint64_t)((sub >> 16) >> SHIFT);
                     }
                 }
-                // ---- refill symbol chunks whose last reader was this step (data is next needed ~U steps from now) ----
-                static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
-                    constexpr int c = decltype(cc)::value;
-                    constexpr int last_use = (16 * c + 15) / BPS;          // step of this block that reads byte 16c+15
-                    constexpr int first_use = (16 * c) / BPS;
-                    if constexpr (last_use == u) {
-                        if (t0 + U + first_use < a.n_steps) {
-                            const u32 o = (t0 + U) * BPS + 16 * c;
-                            cA[c] = load_chunk(rsrc, offA + o, misA, fix);
-                            cB[c] = load_chunk(rsrc, offB + o, misB, fix);
-                        }
-                    }
-                });
             }
         });
-    }
+    };
+    for (; t0 + U <= a.n_steps; t0 += U) block(std::false_type{});
+    if (t0 < a.n_steps) block(std::true_type{});
+
     if constexpr (DW != 4) {
         if (a.n_steps % SPS != 0) ws_tile[(size_t)(a.n_steps / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
     }
@@ -392,12 +439,13 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
             constexpr u32 r = decltype(rc)::value;
             const u32 x = (q << REG_BITS) | r;
             const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;   // state held by slot x after n_steps steps
+            const u32 v = m[r] ^ BIAS2;
             if (SHIFT) {
-                if (validA) ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((m[r] & 0xFFFFu) >> 8);
-                if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(m[r] >> 24);
+                if (validA) ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
+                if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(v >> 24);
             } else {
-                if (validA) ((uint16_t*)a.metrics_out)[(size_t)fA * N + s] = (uint16_t)(m[r] & 0xFFFFu);
-                if (validB) ((uint16_t*)a.metrics_out)[(size_t)fB * N + s] = (uint16_t)(m[r] >> 16);
+                if (validA) ((uint16_t*)a.metrics_out)[(size_t)fA * N + s] = (uint16_t)(v & 0xFFFFu);
+                if (validB) ((uint16_t*)a.metrics_out)[(size_t)fB * N + s] = (uint16_t)(v >> 16);
             }
         });
     }
@@ -451,7 +499,7 @@ __global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) {
         const u32 state = reg >> SHIFT_STATE;
         const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
         const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
-        const u32 mine = (w >> ((rs & 15u) + 16u * half)) & 1u;               // candidate from this lane's slice
+        const u32 mine = (w >> SP::dec_bit(rs, (u32)half)) & 1u;                // candidate from this lane's slice
         const u32 bit = (u32)__shfl((int)mine, (int)(qs * 16 + g));           // the slice that owns slot x
         reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
     };
@@ -528,7 +576,7 @@ __global__ void reg_export_kernel(RegExportArgs a) {
         const size_t row = (size_t)tile * a.ws_tile_stride + (size_t)(t / SPS) * 64 + qs * 16 + g;
         const u32 dwi = (DW == 4) ? (rs >> 4) : (t % SPS) * DW + (rs >> 4);
         const u32 v = a.ws32[row * 4 + dwi];
-        word |= (uint64_t)((v >> ((rs & 15u) + 16u * half)) & 1u) << b;
+        word |= (uint64_t)((v >> SP::dec_bit(rs, half)) & 1u) << b;
     }
     a.out[idx] = word;
 }
