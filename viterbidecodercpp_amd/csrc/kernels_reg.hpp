@@ -119,8 +119,8 @@ struct RegSpec {
         return p;
     }
     // position of the decision bit of slot register r (frame half h) inside its decision dword r/16: the sign bits of
-    // register pairs (2k, 2k+1) are byte-gathered, so even registers land in bytes 0/1 (frame A/B), odd ones in bytes 2/3
-    static constexpr u32 dec_bit(u32 r, u32 h) { return ((r & 15u) >> 1) + 8u * h + 16u * (r & 1u); }
+    // register pairs (r, r+8) are byte-gathered: byte 0/1 = registers 0-7 of frame A/B, byte 2/3 = registers 8-15 of A/B
+    static constexpr u32 dec_bit(u32 r, u32 h) { return (r & 7u) + 8u * h + 16u * ((r >> 3) & 1u); }
     // slot bit exchanged by the butterflies of phase ph, and whether that is a lane bit
     static constexpr int pbit(int ph) { return SB - 1 - ph; }
     static constexpr bool lane_phase(int ph) { return pbit(ph) >= REG_BITS; }
@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     const u32 THRM1B2 = ((u32)(uint16_t)(a.cfg.threshold - 1) * 0x10001u) ^ BIAS2;
     const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
     const u32 MASKQ = q == 0 ? BIAS2 : 0u;   // state 0 is slot 0: lane group q == 0, register 0
+    // v_perm selectors {own = bytes 4-7, partner = bytes 0-3} for the half-dword exchange after a lane-bit phase
+    const u32 SELX32 = (lane & 32) ? 0x07060302u : 0x01000504u;
+    const u32 SELX16 = (lane & 16) ? 0x07060302u : 0x01000504u;
 
     // the branch pattern contributed by this lane's group q is folded in by exchanging `high` and `low` per polynomial:
     // per-lane constants, one pair per (phase, polynomial)
@@ -359,24 +362,30 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                 });
                 // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
                 const u32 need = (pk_sub_sat_s(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
-                // ---- gather the 2 x NREG sign bits: bytes 1 and 3 of a register pair -> one dword, 8 pairs per dword ----
+                // ---- gather the 2 x NREG sign bits: bytes 1 and 3 of the register pair (r, r+8) -> one dword per 16 registers:
+                //      byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B registers 8-15, register k at bit k%8 ----
                 constexpr u32 SIGNS = 0x80808080u;
-                constexpr u32 HI_BYTES = 0x07050301u;   // {D[r].b1, D[r].b3, D[r+1].b1, D[r+1].b3}
+                constexpr u32 HI_BYTES = 0x07050301u;   // {D[r].b1, D[r].b3, D[r+8].b1, D[r+8].b3}
                 u32 acc[DW];
                 static_for<DW>([&](auto dc) __attribute__((always_inline)) {
                     constexpr int d = decltype(dc)::value;
-                    // two independent 4-deep chains instead of one 8-deep: pair k ends at bit k of each byte
+                    // two independent 4-deep shift-in chains instead of one 8-deep
                     u32 lo4 = 0, hi4 = 0;
                     static_for<4>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
-                        constexpr int r = 16 * d + 2 * k;
-                        lo4 = (__builtin_amdgcn_perm(D[r + 1], D[r], HI_BYTES) & SIGNS) | (lo4 >> 1);
-                        hi4 = (__builtin_amdgcn_perm(D[r + 9], D[r + 8], HI_BYTES) & SIGNS) | (hi4 >> 1);
+                        constexpr int r = 16 * d + k;
+                        lo4 = (__builtin_amdgcn_perm(D[r + 8], D[r], HI_BYTES) & SIGNS) | (lo4 >> 1);
+                        hi4 = (__builtin_amdgcn_perm(D[r + 12], D[r + 4], HI_BYTES) & SIGNS) | (hi4 >> 1);
                     });
-                    // NREG == 16 in a lane phase: registers 0-7 / 8-15 belong to different lanes until the exchange is undone
-                    if constexpr (LP && NREG == 16) lane_swap(lo4, hi4);
                     acc[d] = (lo4 >> 4) | hi4;
                 });
+                if constexpr (LP && NREG == 16) {
+                    // registers 0-7 / 8-15 (low / high half of the dword) belong to different lanes until the exchange is
+                    // undone: lane bit 0 keeps its low half and takes the partner's low half as its high half; lane bit 1
+                    // takes the partner's high half as its low half and keeps its high half
+                    const u32 partner = (u32)__shfl_xor((int)acc[0], LB == 1 ? 32 : 16);
+                    acc[0] = __builtin_amdgcn_perm(acc[0], partner, LB == 1 ? SELX32 : SELX16);
+                }
                 if constexpr (LP && NREG > 16) {
                     static_for<DW / 2>([&](auto dc) __attribute__((always_inline)) {
                         constexpr int d = decltype(dc)::value;
@@ -547,6 +556,95 @@ __global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) {
     }
 }
 
+// ---- lane-local chainback for the 16-register codes (K = 7): one lane per frame, 64 frames (two tiles) per wave ------
+// Nothing on the dependent bit-chase leaves the lane: the four q-rows of a step (16 B each, 4 steps per row) are all loaded
+// by the frame's lane, two v_perm pick this frame's bytes into a 64-bit word whose bit index IS the slot index, and the
+// survivor's bit is one shift away.  Rows are fetched NBUF groups (4 steps each) ahead of the chase into a register ring
+// (28 x 1 KiB loads in flight per wave); the main loop is branch-free so that hipcc can retire the ring with counted
+// s_waitcnt vmcnt(N) instead of draining it (a branch around a load costs a vmcnt(0)).
+template <class SP>
+__global__ void __launch_bounds__(64) reg_chainback16_kernel(RegChainbackArgs a) {
+    static_assert(SP::NREG == 16 && SP::DW == 1 && SP::SPS == 4 && SP::SB == 6, "K = 7 layout");
+    constexpr int SB = SP::SB;
+    constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
+    constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
+    constexpr int NBUF = 8;                                    // even: keeps the byte-output positions compile-time
+
+    const int lane = threadIdx.x & 63;
+    const u32 f_raw = blockIdx.x * 64 + lane;
+    const bool valid = f_raw < a.frames;
+    const u32 f = valid ? f_raw : a.frames - 1;                // surplus lanes redo the last frame (identical stores)
+    const u32 tile = f >> 5, g = f & 15u, half = (f >> 4) & 1u;
+    const uint4* rows = a.ws + (size_t)tile * a.ws_tile_stride + g;   // row (group, q) = rows[group*64 + q*16]
+    const size_t out_stride = ((size_t)a.L + 7) / 8;
+    uint8_t* out = a.out + (size_t)f * out_stride;
+    // {row q.byte(h), row q.byte(2+h), row q+1.byte(h), row q+1.byte(2+h)}: this frame's 16+16 bits of two q-rows
+    const u32 selh = half | ((2u + half) << 8) | ((4u + half) << 16) | ((6u + half) << 24);
+
+    u32 reg = (a.end_state ? (a.end_state[f] & SP::SMASK) : 0u) << SHIFT_STATE;
+
+    // one traceback step on the four dwords (one per q-row) that hold step t
+    auto chase = [&](u32 d0, u32 d1, u32 d2, u32 d3, u32 ph1) __attribute__((always_inline)) {
+        const u32 lo = __builtin_amdgcn_perm(d1, d0, selh), hi = __builtin_amdgcn_perm(d3, d2, selh);
+        const u32 state = reg >> SHIFT_STATE;
+        const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
+        const u32 w = (x & 32u) ? hi : lo;
+        const u32 bit = (w >> (x & 31u)) & 1u;
+        reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
+    };
+    auto emit = [&](u32 jb) __attribute__((always_inline)) {    // byte jb is complete
+        out[jb] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+    };
+    // ragged ends: load the step's dwords directly (dependent latency, only a handful of steps)
+    auto slow_step = [&](int t) __attribute__((always_inline)) {
+        const u32* r32 = (const u32*)(rows + (size_t)(t >> 2) * 64) + (t & 3);
+        chase(r32[0], r32[16 * 4], r32[32 * 4], r32[48 * 4], (u32)((t + 1) % SB));
+        const int j = t - SB;
+        if ((j & 7) == 0) emit((u32)j >> 3);
+    };
+
+    int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
+    // top: down to a group boundary, and to an EVEN group on top of the ring
+    while (t >= SB && (((t & 3) != 3) || (((t >> 2) & 1) != 0))) slow_step(t--);
+    const int g_top = t >> 2;                                   // even (or the loop above ran out of steps)
+    const int g_min = (SB + 3) / 4;                             // lowest group whose 4 steps are all >= SB
+    if (t >= SB && g_top - (NBUF - 1) >= g_min) {
+        uint4 buf[NBUF][4];
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(g_top - b) * 64 + qq * 16];
+        int gb = g_top;
+        u32 ph = (u32)((4 * gb + 3 + 1) % SB);                  // (t+1) % SB of the first step of the ring
+        for (; gb - (NBUF - 1) >= g_min; gb -= NBUF) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                const int grp = gb - b;                         // parity == parity of b (gb is even)
+#pragma unroll
+                for (int sidx = 3; sidx >= 0; --sidx) {
+                    const u32 d0 = sidx == 0 ? buf[b][0].x : sidx == 1 ? buf[b][0].y : sidx == 2 ? buf[b][0].z : buf[b][0].w;
+                    const u32 d1 = sidx == 0 ? buf[b][1].x : sidx == 1 ? buf[b][1].y : sidx == 2 ? buf[b][1].z : buf[b][1].w;
+                    const u32 d2 = sidx == 0 ? buf[b][2].x : sidx == 1 ? buf[b][2].y : sidx == 2 ? buf[b][2].z : buf[b][2].w;
+                    const u32 d3 = sidx == 0 ? buf[b][3].x : sidx == 1 ? buf[b][3].y : sidx == 2 ? buf[b][3].z : buf[b][3].w;
+                    chase(d0, d1, d2, d3, ph);
+                    ph = ph == 0 ? SB - 1 : ph - 1;
+                    // j = 4*grp + sidx - 6 is a multiple of 8  <=>  grp odd and sidx == 2.  Unconditional byte store: a
+                    // branch (or a dword accumulator with a data-dependent flush) here would cost the ring its counted waits
+                    if ((b & 1) == 1 && sidx == 2) out[(u32)(4 * grp + sidx - SB) >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+                }
+                const int nxt = grp - NBUF;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16];
+                // keep the refill where it is written: hipcc otherwise sinks/merges the loads and the ring loses its depth
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        t = 4 * gb + 3;
+    }
+    // bottom: what the ring did not cover
+    while (t >= SB) slow_step(t--);
+}
+
 // ---- export to the reference layout [F][n_steps][W] ----------------------------------------------------------------
 struct RegExportArgs {
     const u32* ws32;
@@ -640,7 +738,11 @@ template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a,
 }
 template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
-    hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    if constexpr (SP::NREG == 16) {
+        hipLaunchKernelGGL(reg_chainback16_kernel<SP>, dim3((a.frames + 63) / 64), dim3(64), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
