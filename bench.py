@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--code", type=int, default=2, help="index into COMMON_CODES (2 = Voyager K=7 R=1/2)")
     ap.add_argument("--decode-type", default="SOFT16")
     ap.add_argument("--ebn0", type=float, default=3.0)
-    ap.add_argument("--plan", default="auto", choices=["auto", "lds", "reg"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "lds", "reg", "lds2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -116,7 +116,7 @@ def main():
             buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
         dist.broadcast(buf, src=0)
         blob = bytes(buf.cpu().numpy().tobytes())
-    plan = {"auto": _lib.PLAN_AUTO, "lds": _lib.PLAN_LDS, "reg": _lib.PLAN_REG}[args.plan]
+    plan = {"auto": _lib.PLAN_AUTO, "lds": _lib.PLAN_LDS, "reg": _lib.PLAN_REG, "lds2": _lib.PLAN_LDS2}[args.plan]
     dec = BatchDecoder(device=local_rank, blob=blob, plan=plan)
 
     # ---- synthetic frames, generated directly in HBM (not timed) ----

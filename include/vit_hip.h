@@ -48,7 +48,9 @@ extern "C" {
 /* kernel plans (vit_hip_set_plan): which device implementation serves update()/chainback() */
 #define VIT_HIP_PLAN_AUTO 0
 #define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
-#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, 4 lanes per frame pair (K = 7, 9 codes)              */
+#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, 4 lanes per frame pair (K = 7, 9 stock codes)        */
+#define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, butterfly per thread, u32 metrics double-buffered in LDS
+                               (K = 11..15, R <= 6, any polynomials)                                                  */
 
 typedef struct vit_hip_decoder* vit_hip_handle;
 typedef void* vit_hip_stream_t;
@@ -58,7 +60,7 @@ typedef struct vit_hip_info {
     int32_t num_states;      /* N */
     int32_t decision_words;  /* W */
     int32_t device;
-    int32_t plan;            /* resolved plan (VIT_HIP_PLAN_LDS / _REG) */
+    int32_t plan;            /* resolved plan (VIT_HIP_PLAN_LDS / _REG / _LDS2) */
     int32_t soft_decision_high, soft_decision_low; /* recovered from the branch table */
     uint32_t polynomials[16];                      /* recovered G[i] (bit 0 and bit K-1 forced to 1), 0 if not linear */
     int32_t table_is_linear;

@@ -34,6 +34,20 @@ def test_auto_plan_matrix(oracle, code, decode_type):
     check_batch_against_oracle(oracle, code, decode_type, F + 2, L, default_ebn0(code, decode_type), seed=11)
 
 
+@pytest.mark.parametrize("decode_type", DECODE_TYPES)
+@pytest.mark.parametrize("K,R,G", [(11, 2, (0b10011011001, 0b11110110101)), (13, 3, (0o10533, 0o10675, 0o17661)),
+                                   (12, 2, (0o4335, 0o5723)), (14, 2, (0o21645, 0o35661)), (15, 6, COMMON_CODES[7].G)])
+def test_lds2_plan_large_k(oracle, K, R, G, decode_type):
+    """PLAN_LDS2 (packed frame pair in LDS) on K = 11..15, including non-stock polynomials; odd frame count."""
+    from viterbidecodercpp_amd import Code
+    code = Code(f"K{K}R{R}", K, R, tuple(G))
+    dec = check_batch_against_oracle(oracle, code, decode_type, 3, 48 if K >= 14 else 128, -2.0 if K >= 14 else 2.0, seed=K,
+                                     plan=_lib.PLAN_LDS2)
+    assert dec.plan == _lib.PLAN_LDS2
+    dec2 = check_batch_against_oracle(oracle, code, decode_type, 2, 40, 1.0, seed=K + 1, plan=_lib.PLAN_LDS)
+    assert dec2.plan == _lib.PLAN_LDS
+
+
 @pytest.mark.parametrize("code_id", [2, 5])
 def test_noise_free_round_trip(oracle, code_id):
     """the reference's own test property (run_tests.cpp:184-186): clean frame decodes with 0 bit errors."""

@@ -13,8 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libvit_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NO_DEVICE, ERR_WORKSPACE = -1, -2, -3, -4, -5
-PLAN_AUTO, PLAN_LDS, PLAN_REG = 0, 1, 2
-PLAN_NAMES = {PLAN_LDS: "lds", PLAN_REG: "reg"}
+PLAN_AUTO, PLAN_LDS, PLAN_REG, PLAN_LDS2 = 0, 1, 2, 3
+PLAN_NAMES = {PLAN_LDS: "lds", PLAN_REG: "reg", PLAN_LDS2: "lds2"}
 
 # every symbol include/vit_hip.h declares
 EXPORTS = [

@@ -12,6 +12,7 @@
 
 #include "../../include/vit_hip.h"
 #include "kernels_lds.hpp"
+#include "kernels_lds2.hpp"
 #include "kernels_reg.hpp"
 
 namespace {
@@ -65,6 +66,7 @@ struct vit_hip_decoder {
     uint16_t* d_pattern = nullptr;
     vit::RegCode reg_code{};        // PLAN_REG description (valid when reg_ok)
     bool reg_ok = false;
+    bool lds2_ok = false;
     // host-route scratch
     hipStream_t stream = nullptr;
     void* d_scratch = nullptr;
@@ -260,7 +262,8 @@ int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* br
         return fail(VIT_HIP_ERR_RUNTIME, "device allocation failed in vit_hip_create");
     }
     h->reg_ok = h->linear && vit::reg_code_supported(K, R) && vit::reg_code_init(&h->reg_code, K, R, h->G, h->cfg);
-    h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : VIT_HIP_PLAN_LDS;
+    h->lds2_ok = vit::lds2_supported(K, R);
+    h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
     *out = h;
     return VIT_HIP_OK;
 }
@@ -288,10 +291,13 @@ int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
 
 int vit_hip_set_plan(vit_hip_handle h, int plan) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
-    if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : VIT_HIP_PLAN_LDS;
+    if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
     if (plan == VIT_HIP_PLAN_REG && !h->reg_ok)
         return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG serves only the register-resident instantiations (see kernels_reg.hpp)");
-    if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG) return fail(VIT_HIP_ERR_INVALID_ARG, "unknown plan");
+    if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 11..15 with R <= 6 (see kernels_lds2.hpp)");
+    if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG && plan != VIT_HIP_PLAN_LDS2)
+        return fail(VIT_HIP_ERR_INVALID_ARG, "unknown plan");
     h->plan = plan;
     return VIT_HIP_OK;
 }
@@ -335,6 +341,7 @@ int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vi
 size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L) {
     if (!h) return 0;
     if (h->plan == VIT_HIP_PLAN_REG) return vit::reg_workspace_bytes(h->reg_code, frames, L);
+    if (h->plan == VIT_HIP_PLAN_LDS2) return align_up(vit::lds2_workspace_bytes(h->K, frames, L), 256);
     return align_up(frames * (L + (size_t)h->K - 1) * (size_t)h->W * 8, 256);
 }
 
@@ -358,6 +365,12 @@ int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames,
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan update launch failed");
         return VIT_HIP_OK;
     }
+    if (h->plan == VIT_HIP_PLAN_LDS2) {
+        const int rc = vit::lds2_update(h->K, h->R, h->cfg, h->shift, h->d_pattern, d_symbols, frames, n_steps, L, d_workspace,
+                                        d_final_metrics, d_renorm_sum, d_start_state, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "PLAN_LDS2 update launch failed");
+        return VIT_HIP_OK;
+    }
     return lds_update(h, d_symbols, frames, n_steps, L + (size_t)h->K - 1, 0, (uint64_t*)d_workspace, d_final_metrics,
                       true, d_renorm_sum, d_start_state, st);
 }
@@ -373,6 +386,11 @@ int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t fr
     if (h->plan == VIT_HIP_PLAN_REG) {
         const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
+        return VIT_HIP_OK;
+    }
+    if (h->plan == VIT_HIP_PLAN_LDS2) {
+        const int rc = vit::lds2_chainback(h->K, d_workspace, frames, L, d_bytes_out, d_end_state, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "PLAN_LDS2 chainback launch failed");
         return VIT_HIP_OK;
     }
     return lds_chainback(h, (const uint64_t*)d_workspace, frames, L, d_bytes_out, d_end_state, st);
@@ -400,6 +418,11 @@ int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t f
     if (h->plan == VIT_HIP_PLAN_REG) {
         const int rc = vit::reg_export(h->reg_code, d_workspace, frames, n_steps, L, d_decisions, st);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan export launch failed");
+        return VIT_HIP_OK;
+    }
+    if (h->plan == VIT_HIP_PLAN_LDS2) {
+        const int rc = vit::lds2_export(h->K, d_workspace, frames, n_steps, L, d_decisions, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "PLAN_LDS2 export launch failed");
         return VIT_HIP_OK;
     }
     const size_t rows = L + (size_t)h->K - 1;
