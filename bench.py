@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--plan", default="auto", choices=["auto", "lds", "reg", "lds2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -85,15 +88,19 @@ def main():
     import torch.distributed as dist
 
     from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, _lib,
-                                       get_decoding_config, pack_blob, synth)
+                                       dist as vdist, get_decoding_config, pack_blob, synth)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
 
     code = COMMON_CODES[args.code]
     pc = get_decoding_config(args.decode_type, code.R)
@@ -102,20 +109,12 @@ def main():
     W = code.decision_words
 
     # ---- the shared branch table: built on rank 0, broadcast as one small blob (RCCL over xGMI), rebuilt everywhere ----
+    blob = None
     if rank == 0:
         table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
         config = ViterbiDecoder_Config.from_decoder_config(pc)
         blob = pack_blob(table, config)
-        n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
-    else:
-        blob, n = None, torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(n, src=0)
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
-        dist.broadcast(buf, src=0)
-        blob = bytes(buf.cpu().numpy().tobytes())
+    blob = vdist.broadcast_blob(blob, src=0, device=coll_dev)
     plan = {"auto": _lib.PLAN_AUTO, "lds": _lib.PLAN_LDS, "reg": _lib.PLAN_REG, "lds2": _lib.PLAN_LDS2}[args.plan]
     dec = BatchDecoder(device=local_rank, blob=blob, plan=plan)
 
@@ -149,7 +148,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
