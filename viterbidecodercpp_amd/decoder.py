@@ -226,13 +226,21 @@ class BatchDecoder:
     def workspace_bytes(self, frames: int, L: int) -> int:
         return _lib.load().vit_hip_workspace_bytes(self._handle._h, frames, L)
 
-    def _workspace(self, frames, L):
+    def _workspace(self, frames, L, workspace=None):
         need = self.workspace_bytes(frames, L)
+        if workspace is not None:
+            if workspace.numel() * workspace.element_size() < need or workspace.data_ptr() % 256 != 0:
+                raise ValueError("workspace too small or not 256-byte aligned")
+            return workspace
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
         assert self._ws.data_ptr() % 256 == 0
         return self._ws
+
+    def new_workspace(self, frames: int, L: int):
+        """a private decision workspace (for double-buffered pipelines: update of batch i+1 beside chainback of batch i)."""
+        return self.torch.empty(self.workspace_bytes(frames, L), dtype=self.torch.uint8, device=self.device)
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -248,13 +256,13 @@ class BatchDecoder:
         return frames
 
     def update(self, symbols, L: int, n_steps: int = None, start_state=None, want_metrics=True, metrics_out=None,
-               renorm_out=None):
+               renorm_out=None, workspace=None):
         """reset + update over n_steps (default L+K-1) steps.  returns (final_metrics [F][N], renorm_sum [F]);
         with want_metrics=False and no *_out buffers nothing but the decision workspace is written."""
         t = self.torch
         n_steps = (L + self.K - 1) if n_steps is None else n_steps
         frames = self._check_symbols(symbols, n_steps)
-        ws = self._workspace(frames, L)
+        ws = self._workspace(frames, L, workspace)
         edt = t.int16 if self.error_bytes == 2 else t.uint8  # int16 carries the uint16 bit pattern
         met, rs = metrics_out, renorm_out
         if want_metrics:
@@ -264,14 +272,15 @@ class BatchDecoder:
         if start_state is not None:
             ss = t.as_tensor(start_state, dtype=t.int32, device=self.device).contiguous()
         _lib.check(_lib.load().vit_hip_update_batch(
-            self._handle._h, C.c_void_p(symbols.data_ptr()), frames, n_steps, L, C.c_void_p(ws.data_ptr()), ws.numel(),
+            self._handle._h, C.c_void_p(symbols.data_ptr()), frames, n_steps, L, C.c_void_p(ws.data_ptr()),
+            ws.numel() * ws.element_size(),
             C.c_void_p(met.data_ptr()) if met is not None else None, C.c_void_p(rs.data_ptr()) if rs is not None else None,
             C.c_void_p(ss.data_ptr()) if ss is not None else None, self._stream()))
         return met, rs
 
-    def chainback(self, frames: int, L: int, end_state=None, out=None):
+    def chainback(self, frames: int, L: int, end_state=None, out=None, workspace=None):
         t = self.torch
-        ws = self._workspace(frames, L)
+        ws = self._workspace(frames, L, workspace)
         if out is None:
             out = t.empty((frames, (L + 7) // 8), dtype=t.uint8, device=self.device)
         es = None
