@@ -1,0 +1,103 @@
+"""C-ABI behaviour on the GPU box: error codes (no exceptions, no crashes), plan selection, workspace checks, empty and
+degenerate batches, handle reuse across batches of different sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib,
+                                   get_decoding_config, synth)
+from tests.helpers import check_batch_against_oracle, make_table_config
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plan_selection_and_errors():
+    lib = _lib.load()
+    expect = {0: _lib.PLAN_LDS, 1: _lib.PLAN_LDS, 2: _lib.PLAN_REG, 3: _lib.PLAN_REG, 4: _lib.PLAN_REG, 5: _lib.PLAN_REG,
+              6: _lib.PLAN_REG, 7: _lib.PLAN_LDS2}
+    for cid, plan in expect.items():
+        pc, table, config = make_table_config(COMMON_CODES[cid], "SOFT16")
+        dec = BatchDecoder(table, config)
+        assert dec.plan == plan, COMMON_CODES[cid].name
+        info = dec._handle.info
+        assert list(info.polynomials[:COMMON_CODES[cid].R]) == list(COMMON_CODES[cid].G) and info.table_is_linear == 1
+        assert (info.soft_decision_high, info.soft_decision_low) == (127, -127)
+    # K=7 with non-stock polynomials: served by the LDS plan, REG refused
+    code = Code("custom", 7, 2, (0o171, 0o133))
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    assert dec.plan == _lib.PLAN_LDS
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_LDS2) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_set_plan(dec._handle._h, 99) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_AUTO) == _lib.OK
+
+
+def test_custom_polynomials_decode(oracle):
+    code = Code("NASA K=7 (171,133)", 7, 2, (0o171, 0o133))
+    check_batch_against_oracle(oracle, code, "SOFT16", 5, 512, 2.0, seed=21)
+    code = Code("K=9 R=1/3 custom", 9, 3, (0o557, 0o663, 0o711))
+    check_batch_against_oracle(oracle, code, "HARD8", 3, 256, 4.0, seed=22)
+    code = Code("K=4 R=1/2", 4, 2, (0o15, 0o17))
+    check_batch_against_oracle(oracle, code, "SOFT8", 4, 256, 3.0, seed=23)
+    code = Code("K=2 R=1/2", 2, 2, (0b11, 0b11))
+    check_batch_against_oracle(oracle, code, "SOFT16", 2, 64, 3.0, seed=24)
+
+
+def test_workspace_and_argument_checks():
+    import torch
+
+    lib = _lib.load()
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    F, L = 4, 64
+    _, sym = synth.make_frames_numpy(code, pc, F, L, 3.0, seed=1)
+    d_sym = torch.from_numpy(sym).cuda()
+    need = dec.workspace_bytes(F, L)
+    ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
+    h = dec._handle._h
+    p = lambda t, off=0: C.c_void_p(t.data_ptr() + off)  # noqa: E731
+    S = L + code.K - 1
+    assert lib.vit_hip_update_batch(h, p(d_sym), F, S, L, p(ws), need - 1, None, None, None, None) == _lib.ERR_WORKSPACE
+    assert lib.vit_hip_update_batch(h, p(d_sym), F, S, L, p(ws, 16), need, None, None, None, None) == _lib.ERR_WORKSPACE
+    assert lib.vit_hip_update_batch(h, p(d_sym), F, S + 1, L, p(ws), need, None, None, None, None) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_update_batch(h, None, F, S, L, p(ws), need, None, None, None, None) == _lib.ERR_INVALID_ARG
+    assert b"NULL" in lib.vit_hip_last_error()
+    assert lib.vit_hip_update_batch(h, p(d_sym), 0, S, L, p(ws), need, None, None, None, None) == _lib.OK   # empty batch
+    assert lib.vit_hip_chainback_batch(h, p(ws), 0, L, p(out), None, None) == _lib.OK
+    assert lib.vit_hip_decode_batch(h, p(d_sym), F, L, p(ws), need, p(out), None, None, None, None) == _lib.OK
+    torch.cuda.synchronize()
+    assert lib.vit_hip_destroy(None) == _lib.OK
+
+
+def test_handle_reuse_across_batch_shapes(oracle):
+    """one decoder, many batches: sizes change, results stay exact (workspace re-used and re-grown)."""
+    import torch
+    from oracle import pyoracle
+
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    ocfg = pyoracle.stock_config(pyoracle.SOFT16, code.R)
+    for F, L in [(33, 256), (1, 8), (70, 1024), (2, 64), (64, 512)]:
+        tx, sym = synth.make_frames_numpy(code, pc, F, L, 2.0, seed=F + L)
+        out = dec.decode(torch.from_numpy(sym).cuda(), L).cpu().numpy()
+        want, _, _ = oracle.decode_frames(code.K, code.R, code.G, ocfg, sym, L, threads=4)
+        assert np.array_equal(out, want), (F, L)
+
+
+def test_blob_round_trip_builds_identical_decoder(oracle):
+    import torch
+    from viterbidecodercpp_amd import pack_blob
+
+    code = COMMON_CODES[5]
+    pc, table, config = make_table_config(code, "HARD8")
+    a = BatchDecoder(table, config)
+    b = BatchDecoder(blob=pack_blob(table, config))
+    assert (a.K, a.R, a.plan, a.soft_bytes) == (b.K, b.R, b.plan, b.soft_bytes)
+    _, sym = synth.make_frames_numpy(code, pc, 6, 256, 4.0, seed=4)
+    d = torch.from_numpy(sym).cuda()
+    assert torch.equal(a.decode(d, 256), b.decode(d, 256))
