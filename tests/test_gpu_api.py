@@ -101,3 +101,35 @@ def test_blob_round_trip_builds_identical_decoder(oracle):
     _, sym = synth.make_frames_numpy(code, pc, 6, 256, 4.0, seed=4)
     d = torch.from_numpy(sym).cuda()
     assert torch.equal(a.decode(d, 256), b.decode(d, 256))
+
+
+def test_batch_calls_capture_into_a_hip_graph(oracle):
+    """the batch entry points only enqueue work (no allocation, no synchronisation): a decode captured once into a
+    hipGraph (torch.cuda.CUDAGraph) replays on new symbols and stays bit-exact."""
+    import torch
+    from oracle import pyoracle
+
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    F, L = 96, 512
+    ocfg = pyoracle.stock_config(pyoracle.SOFT16, code.R)
+    _, sym0 = synth.make_frames_numpy(code, pc, F, L, 2.0, seed=31)
+    d_sym = torch.from_numpy(sym0).cuda()
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
+    ws = dec.new_workspace(F, L)
+    dec.update(d_sym, L, want_metrics=False, workspace=ws)       # warm-up outside capture
+    dec.chainback(F, L, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        dec.update(d_sym, L, want_metrics=False, workspace=ws)
+        dec.chainback(F, L, out=out, workspace=ws)
+    for seed in (32, 33):
+        _, sym = synth.make_frames_numpy(code, pc, F, L, 2.0, seed=seed)
+        d_sym.copy_(torch.from_numpy(sym))
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        want, _, _ = oracle.decode_frames(code.K, code.R, code.G, ocfg, sym, L, threads=4)
+        assert np.array_equal(out.cpu().numpy(), want)
