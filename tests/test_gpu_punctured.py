@@ -1,0 +1,63 @@
+"""Punctured (DAB fast-information-channel) decode through the streaming interface: the scenario of the reference's
+examples/run_punctured_decoder.cpp.  K=7 R=1/4 mother code, puncturing vectors PI_16 x 21 blocks,
+PI_15 x 3 blocks and the 24-bit tail vector PI_X (ETSI EN 300 401 clause 11.1.2 / 11.2; vectors as listed in
+run_punctured_decoder.cpp:39-76), punctured positions re-inserted as the erasure value 0, update() called with R symbols at
+a time exactly as examples/helpers/puncture_code_helpers.h:17-55 does.  Pass = 0 bit errors on a clean channel (the
+reference's criterion) AND bit-exact agreement with the oracle, clean and noisy."""
+import numpy as np
+import pytest
+
+from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core,
+                                   ViterbiDecoder_HIP, get_decoding_config, synth)
+from tests.helpers import oracle_cfg
+
+pytestmark = pytest.mark.gpu
+
+PI_16 = [1, 1, 1, 0] * 8
+PI_15 = [1, 1, 1, 0] * 7 + [1, 1, 0, 0]
+PI_X = [1, 1, 0, 0] * 6
+TOTAL_DATA_BITS = 768                       # one FIC block of three 256-bit FIBs
+
+
+def puncture_mask(K=7, R=4):
+    mask = (PI_16 * 4) * 21 + (PI_15 * 4) * 3 + PI_X        # 128-symbol blocks, then the tail
+    assert len(mask) == (TOTAL_DATA_BITS + K - 1) * R
+    return np.asarray(mask, dtype=bool)
+
+
+@pytest.mark.parametrize("decode_type", ["SOFT16", "SOFT8", "HARD8"])
+@pytest.mark.parametrize("ebn0", [None, 6.0])
+def test_dab_fic_punctured_streaming(oracle, decode_type, ebn0):
+    import torch
+
+    code = COMMON_CODES[4]                   # DAB Radio K=7 R=1/4
+    pc = get_decoding_config(decode_type, code.R)
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    config = ViterbiDecoder_Config.from_decoder_config(pc)
+    tx, sym = synth.make_frames_numpy(code, pc, 1, TOTAL_DATA_BITS, ebn0, seed=42)
+    mask = puncture_mask()
+    transmitted = sym[0].reshape(-1)[mask]                  # what goes over the air: 2/3 of the mother-code symbols
+    depunctured = np.zeros(mask.size, dtype=pc.soft_dtype)  # erasure value 0 (run_punctured_decoder.cpp:165)
+    depunctured[mask] = transmitted
+    assert transmitted.size == 21 * 4 * 24 + 3 * (4 * 21 + 8) + 12
+
+    want = oracle.decode(code.K, code.R, code.G, oracle_cfg(decode_type, code.R), depunctured, TOTAL_DATA_BITS)
+
+    vitdec = ViterbiDecoder_Core(table, config)
+    vitdec.set_traceback_length(TOTAL_DATA_BITS)
+    vitdec.reset()
+    acc = 0
+    for t in range(0, depunctured.size, code.R):            # R symbols per update() call
+        acc += ViterbiDecoder_HIP.update(vitdec, depunctured[t:t + code.R])
+    rx = vitdec.chainback(TOTAL_DATA_BITS)
+    assert acc == want["renorm_sum"] and vitdec.get_error() == want["error"]
+    assert np.array_equal(vitdec.m_decisions, want["decisions"])
+    assert np.array_equal(rx, want["bytes"])
+    if ebn0 is None:
+        assert np.array_equal(rx, tx[0])                    # 0 incorrect bits, the reference's pass criterion
+
+    # the batched route on the same depunctured stream (many FIC blocks at once in a receiver)
+    dec = BatchDecoder(table, config)
+    batch = np.ascontiguousarray(np.broadcast_to(depunctured.reshape(1, -1, code.R), (40, depunctured.size // code.R, code.R)))
+    out = dec.decode(torch.from_numpy(batch).cuda(), TOTAL_DATA_BITS).cpu().numpy()
+    assert all(np.array_equal(out[f], want["bytes"]) for f in range(40))
