@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_plan_selection_and_errors():
     lib = _lib.load()
-    expect = {0: _lib.PLAN_LDS, 1: _lib.PLAN_LDS, 2: _lib.PLAN_REG, 3: _lib.PLAN_REG, 4: _lib.PLAN_REG, 5: _lib.PLAN_REG,
+    expect = {0: _lib.PLAN_REG, 1: _lib.PLAN_REG, 2: _lib.PLAN_REG, 3: _lib.PLAN_REG, 4: _lib.PLAN_REG, 5: _lib.PLAN_REG,
               6: _lib.PLAN_REG, 7: _lib.PLAN_LDS2}
     for cid, plan in expect.items():
         pc, table, config = make_table_config(COMMON_CODES[cid], "SOFT16")

@@ -92,11 +92,16 @@ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 
 // ---- compile-time description of one code -------------------------------------------------------------------------
-template <int K_, int R_, u32 G0, u32 G1, u32 G2, u32 G3>
+template <int K_, int R_, u32 G0, u32 G1, u32 G2, u32 G3, int LANE_BITS_ = 2>
 struct RegSpec {
     static constexpr int K = K_, R = R_;
     static constexpr int SB = K - 1;              // state bits
-    static constexpr int REG_BITS = SB - 2;       // two state-slot bits live in the lane index (lane bits 4 and 5)
+    // LANE_BITS = 2: two state-slot bits live in the lane index (lane bits 4 and 5), 16 frame pairs per wave;
+    // LANE_BITS = 0 (small K): every state of a frame pair lives in ONE lane's registers, 64 frame pairs per wave
+    static constexpr int LANE_BITS = LANE_BITS_;
+    static constexpr int PAIRS = 64 >> LANE_BITS;              // frame pairs per wave
+    static constexpr int TILE = 2 * PAIRS;                     // frames per wave
+    static constexpr int REG_BITS = SB - LANE_BITS;
     static constexpr int NREG = 1 << REG_BITS;    // packed metric registers per lane
     static constexpr int DW = NREG >= 16 ? NREG / 16 : 1;  // decision dwords per lane per step
     static constexpr int SPS = 4 / DW;            // steps per 16-byte decision row
@@ -124,12 +129,13 @@ struct RegSpec {
     // slot bit exchanged by the butterflies of phase ph, and whether that is a lane bit
     static constexpr int pbit(int ph) { return SB - 1 - ph; }
     static constexpr bool lane_phase(int ph) { return pbit(ph) >= REG_BITS; }
-    static constexpr int T = REG_BITS - 1;  // register bit a lane bit is exchanged with
+    static constexpr int T = REG_BITS > 0 ? REG_BITS - 1 : 0;  // register bit a lane bit is exchanged with
 
     // pattern contributed by the register index r0 (bit of the butterfly cleared) in phase ph
     static constexpr u32 pat_reg(int ph, u32 r0) { return pat(rotl(r0, ph)); }
     // pattern contributed by lane group q in phase ph
     static constexpr u32 pat_lane(int ph, u32 q) {
+        if (LANE_BITS == 0) return 0;
         if (!lane_phase(ph)) return pat(rotl(q << REG_BITS, ph));
         // after the lane<->register exchange: this lane's bit `lb` stands for slot register bit T, the butterfly bit
         // itself (slot lane bit lb) is 0 for the r0 member; the other lane bit is unchanged
@@ -191,24 +197,25 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
     constexpr int NP = 1 << R;
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
+    constexpr int PAIRS = SP::PAIRS, TILE = SP::TILE;
     const int lane = threadIdx.x & 63;
-    const u32 g = lane & 15, q = lane >> 4;
+    const u32 g = lane & (PAIRS - 1), q = SP::LANE_BITS ? lane >> 4 : 0;
     const size_t tile = blockIdx.x;
-    const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
+    const u32 fA_raw = (u32)tile * TILE + g, fB_raw = fA_raw + PAIRS;
     const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
     const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
 
     // descriptor over [first frame of this tile (rounded down to a dword), end of the symbol buffer): wave-uniform base,
     // 32-bit per-lane offsets
-    const size_t tile_off = tile * 32 * a.sym_frame_stride_bytes;
+    const size_t tile_off = tile * TILE * a.sym_frame_stride_bytes;
     const u32 bmis = (u32)(((uintptr_t)a.symbols + tile_off) & 3u);
     // rounded up to whole dwords: the range check is per dword, and the dword holding the buffer's last bytes must not
     // be dropped (it cannot straddle an allocation granule)
     const size_t remain = (a.sym_total_bytes - tile_off + bmis + 3) & ~(size_t)3;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.symbols + tile_off - bmis), 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain, 0x00020000);
-    const u32 rawA = (fA - (u32)tile * 32) * (u32)a.sym_frame_stride_bytes + bmis;
-    const u32 rawB = (fB - (u32)tile * 32) * (u32)a.sym_frame_stride_bytes + bmis;
+    const u32 rawA = (fA - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis;
+    const u32 rawB = (fB - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis;
     const u32 offA = rawA & ~3u, offB = rawB & ~3u, misA = rawA & 3u, misB = rawB & 3u;
     const bool fix = __builtin_amdgcn_ballot_w64((misA | misB) != 0) != 0;   // wave-uniform
 
@@ -374,8 +381,12 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                     static_for<4>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         constexpr int r = 16 * d + k;
-                        lo4 = (__builtin_amdgcn_perm(D[r + 8], D[r], HI_BYTES) & SIGNS) | (lo4 >> 1);
-                        hi4 = (__builtin_amdgcn_perm(D[r + 12], D[r + 4], HI_BYTES) & SIGNS) | (hi4 >> 1);
+                        auto dreg = [&](auto rc) __attribute__((always_inline)) -> u32 {   // fewer than 16 registers: K < 7
+                            constexpr int rr = decltype(rc)::value;
+                            if constexpr (rr < NREG) return D[rr]; else return 0u;
+                        };
+                        lo4 = (__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), HI_BYTES) & SIGNS) | (lo4 >> 1);
+                        hi4 = (__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), HI_BYTES) & SIGNS) | (hi4 >> 1);
                     });
                     acc[d] = (lo4 >> 4) | hi4;
                 });
@@ -413,14 +424,16 @@ __global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
                 {
                     const u32 need2 = LP ? ((pk_sub_sat_s(THRM1B2, m[0]) | FORCE) & MASKQ) : need;
                     if (__builtin_amdgcn_ballot_w64(need2 != 0) != 0) {
-                        const u32 nq = (u32)__shfl((int)need2, (int)g);
+                        const u32 nq = SP::LANE_BITS ? (u32)__shfl((int)need2, (int)g) : need2;
                         const u32 msk = ((nq & 0x8000u) ? 0x0000FFFFu : 0u) | ((nq & 0x80000000u) ? 0xFFFF0000u : 0u);
                         u32 mn = m[0];
                         static_for<NREG - 1>([&](auto rc) __attribute__((always_inline)) {
                             mn = pk_min_s(mn, m[decltype(rc)::value + 1]);
                         });
-                        mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 16));
-                        mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 32));
+                        if constexpr (SP::LANE_BITS) {
+                            mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 16));
+                            mn = pk_min_s(mn, (u32)__shfl_xor((int)mn, 32));
+                        }
                         const u32 sub = (mn ^ BIAS2) & msk;   // the true (unbiased) minimum of each frame that renormalises
                         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
                             constexpr int r = decltype(rc)::value;
@@ -645,6 +658,73 @@ __global__ void __launch_bounds__(64) reg_chainback16_kernel(RegChainbackArgs a)
     while (t >= SB) slow_step(t--);
 }
 
+// ---- chainback for the small-K codes (LANE_BITS == 0): one lane per frame, 64 frames (half a tile) per wave -----------
+// The frame's pair-lane row (16 B per 4 steps) holds all of its decision bits; same register-ring / branch-free structure
+// as reg_chainback16_kernel.
+template <class SP>
+__global__ void __launch_bounds__(64) reg_chainback0_kernel(RegChainbackArgs a) {
+    static_assert(SP::LANE_BITS == 0 && SP::NREG <= 16 && SP::DW == 1 && SP::SPS == 4, "small-K layout");
+    constexpr int SB = SP::SB;
+    constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
+    constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
+    constexpr int NBUF = 8;
+    constexpr int OUT_PAR = (SB >> 2) & 1, OUT_SIDX = SB & 3;  // byte complete when (group & 1) == OUT_PAR and step%4 == OUT_SIDX
+
+    const int lane = threadIdx.x & 63;
+    const u32 f_raw = blockIdx.x * 64 + lane;
+    const bool valid = f_raw < a.frames;
+    const u32 f = valid ? f_raw : a.frames - 1;                // surplus lanes redo the last frame (identical stores)
+    const u32 tile = f / SP::TILE, g = f % SP::PAIRS, half = (f % SP::TILE) / SP::PAIRS;
+    const uint4* rows = a.ws + (size_t)tile * a.ws_tile_stride + g;   // row of step group grp = rows[grp*64]
+    const size_t out_stride = ((size_t)a.L + 7) / 8;
+    uint8_t* out = a.out + (size_t)f * out_stride;
+    const u32 hshift = 8u * half;
+
+    u32 reg = (a.end_state ? (a.end_state[f] & SP::SMASK) : 0u) << SHIFT_STATE;
+    auto chase = [&](u32 w, u32 ph1) __attribute__((always_inline)) {
+        const u32 state = reg >> SHIFT_STATE;
+        const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot (= register) of `state` after step t
+        const u32 bit = (w >> ((x & 7u) + hshift + 16u * ((x >> 3) & 1u))) & 1u;  // SP::dec_bit(x, half)
+        reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
+    };
+    auto slow_step = [&](int t) __attribute__((always_inline)) {
+        const u32* r32 = (const u32*)(rows + (size_t)(t >> 2) * 64) + (t & 3);
+        chase(r32[0], (u32)((t + 1) % SB));
+        const int j = t - SB;
+        if ((j & 7) == 0) out[(u32)j >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+    };
+
+    int t = (int)a.L - 1 + SB;
+    while (t >= SB && (((t & 3) != 3) || (((t >> 2) & 1) != 0))) slow_step(t--);   // to an even group boundary
+    const int g_top = t >> 2;
+    const int g_min = (SB + 3) / 4;
+    if (t >= SB && g_top - (NBUF - 1) >= g_min) {
+        uint4 buf[NBUF];
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(g_top - b) * 64];
+        int gb = g_top;
+        u32 ph = (u32)((4 * gb + 3 + 1) % SB);
+        for (; gb - (NBUF - 1) >= g_min; gb -= NBUF) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                const int grp = gb - b;                         // parity == parity of b (gb is even)
+#pragma unroll
+                for (int sidx = 3; sidx >= 0; --sidx) {
+                    const u32 w = sidx == 0 ? buf[b].x : sidx == 1 ? buf[b].y : sidx == 2 ? buf[b].z : buf[b].w;
+                    chase(w, ph);
+                    ph = ph == 0 ? SB - 1 : ph - 1;
+                    if ((b & 1) == OUT_PAR && sidx == OUT_SIDX) out[(u32)(4 * grp + sidx - SB) >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+                }
+                const int nxt = grp - NBUF;
+                buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        t = 4 * gb + 3;
+    }
+    while (t >= SB) slow_step(t--);
+}
+
 // ---- export to the reference layout [F][n_steps][W] ----------------------------------------------------------------
 struct RegExportArgs {
     const u32* ws32;
@@ -663,7 +743,7 @@ __global__ void reg_export_kernel(RegExportArgs a) {
     const u32 w = (u32)(idx % W);
     const u32 t = (u32)((idx / W) % a.n_steps);
     const u32 f = (u32)(idx / ((size_t)W * a.n_steps));
-    const u32 tile = f / 32, g = f % 16, half = (f % 32) / 16;
+    const u32 tile = f / SP::TILE, g = f % SP::PAIRS, half = (f % SP::TILE) / SP::PAIRS;
     const int ph1 = (int)((t + 1) % SB);
     uint64_t word = 0;
     for (u32 b = 0; b < 64; ++b) {
@@ -671,7 +751,7 @@ __global__ void reg_export_kernel(RegExportArgs a) {
         if (s > SP::SMASK) break;
         const u32 x = ((s >> ph1) | (s << (SB - ph1))) & SP::SMASK;
         const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
-        const size_t row = (size_t)tile * a.ws_tile_stride + (size_t)(t / SPS) * 64 + qs * 16 + g;
+        const size_t row = (size_t)tile * a.ws_tile_stride + (size_t)(t / SPS) * 64 + qs * SP::PAIRS + g;
         const u32 dwi = (DW == 4) ? (rs >> 4) : (t % SPS) * DW + (rs >> 4);
         const u32 v = a.ws32[row * 4 + dwi];
         word |= (uint64_t)((v >> SP::dec_bit(rs, half)) & 1u) << b;
@@ -685,23 +765,29 @@ using Spec_K7R3 = RegSpec<7, 3, 91, 117, 121, 0>;           // LTE              
 using Spec_K7R4 = RegSpec<7, 4, 109, 79, 83, 109>;          // DAB Radio        (:25)
 using Spec_K9R2 = RegSpec<9, 2, 491, 369, 0, 0>;            // CDMA IS-95A      (:26)
 using Spec_K9R4 = RegSpec<9, 4, 501, 441, 331, 315>;        // CDMA 2000        (:27)
+using Spec_K3R2 = RegSpec<3, 2, 7, 5, 0, 0, 0>;             // Basic K=3        (:21)  all 4 states in one lane
+using Spec_K5R2 = RegSpec<5, 2, 23, 25, 0, 0, 0>;           // Basic K=5        (:22)  all 16 states in one lane
 
 struct RegCode {
-    int id = -1;   // 0..4 in the order above
+    int id = -1;   // 0..6 in the order above
     int K = 0, R = 0;
+    int tile = 32; // frames per wavefront
 };
 
-inline bool reg_code_supported(int K, int R) { return (K == 7 && R >= 2 && R <= 4) || (K == 9 && (R == 2 || R == 4)); }
+inline bool reg_code_supported(int K, int R) {
+    return (K == 7 && R >= 2 && R <= 4) || (K == 9 && (R == 2 || R == 4)) || ((K == 3 || K == 5) && R == 2);
+}
 
 inline bool reg_code_init(RegCode* rc, int K, int R, const uint32_t* G, const DevConfig&) {
     struct Entry { int K, R; uint32_t G[4]; };
-    static const Entry table[5] = {{7, 2, {109, 79, 0, 0}}, {7, 3, {91, 117, 121, 0}}, {7, 4, {109, 79, 83, 109}},
-                                   {9, 2, {491, 369, 0, 0}}, {9, 4, {501, 441, 331, 315}}};
-    for (int id = 0; id < 5; ++id) {
+    static const Entry table[7] = {{7, 2, {109, 79, 0, 0}}, {7, 3, {91, 117, 121, 0}}, {7, 4, {109, 79, 83, 109}},
+                                   {9, 2, {491, 369, 0, 0}}, {9, 4, {501, 441, 331, 315}},
+                                   {3, 2, {7, 5, 0, 0}}, {5, 2, {23, 25, 0, 0}}};
+    for (int id = 0; id < 7; ++id) {
         if (table[id].K != K || table[id].R != R) continue;
         bool same = true;
         for (int i = 0; i < R; ++i) same = same && (table[id].G[i] == G[i]);
-        if (same) { rc->id = id; rc->K = K; rc->R = R; return true; }
+        if (same) { rc->id = id; rc->K = K; rc->R = R; rc->tile = K < 7 ? 128 : 32; return true; }
     }
     return false;
 }
@@ -711,9 +797,9 @@ inline size_t reg_groups(const RegCode& rc, size_t L) {
     const size_t sps = rc.K == 9 ? 1 : 4;
     return (S + sps - 1) / sps;
 }
-inline size_t reg_tiles(size_t frames) { return (frames + 31) / 32; }
+inline size_t reg_tiles(const RegCode& rc, size_t frames) { return (frames + (size_t)rc.tile - 1) / (size_t)rc.tile; }
 inline size_t reg_workspace_bytes(const RegCode& rc, size_t frames, size_t L) {
-    return reg_tiles(frames) * reg_groups(rc, L) * 1024;
+    return reg_tiles(rc, frames) * reg_groups(rc, L) * 1024;
 }
 
 // The kernels are instantiated one code per translation unit (reg_inst.hip, compiled with -DVIT_REG_ID=0..4) so that the
@@ -724,6 +810,8 @@ template <> struct RegSpecOf<1> { using type = Spec_K7R3; };
 template <> struct RegSpecOf<2> { using type = Spec_K7R4; };
 template <> struct RegSpecOf<3> { using type = Spec_K9R2; };
 template <> struct RegSpecOf<4> { using type = Spec_K9R4; };
+template <> struct RegSpecOf<5> { using type = Spec_K3R2; };
+template <> struct RegSpecOf<6> { using type = Spec_K5R2; };
 
 template <int ID> int reg_launch_update(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st);
 template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st);
@@ -738,7 +826,9 @@ template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a,
 }
 template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
-    if constexpr (SP::NREG == 16) {
+    if constexpr (SP::LANE_BITS == 0) {
+        hipLaunchKernelGGL(reg_chainback0_kernel<SP>, dim3((a.frames + 63) / 64), dim3(64), 0, st, a);
+    } else if constexpr (SP::NREG == 16) {
         hipLaunchKernelGGL(reg_chainback16_kernel<SP>, dim3((a.frames + 63) / 64), dim3(64), 0, st, a);
     } else {
         hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
@@ -756,16 +846,22 @@ template <> int reg_launch_update<1>(int, const RegUpdateArgs&, unsigned, hipStr
 template <> int reg_launch_update<2>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_update<3>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_update<4>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<5>(int, const RegUpdateArgs&, unsigned, hipStream_t);
+template <> int reg_launch_update<6>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_chainback<0>(const RegChainbackArgs&, unsigned, hipStream_t);
 template <> int reg_launch_chainback<1>(const RegChainbackArgs&, unsigned, hipStream_t);
 template <> int reg_launch_chainback<2>(const RegChainbackArgs&, unsigned, hipStream_t);
 template <> int reg_launch_chainback<3>(const RegChainbackArgs&, unsigned, hipStream_t);
 template <> int reg_launch_chainback<4>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<5>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<6>(const RegChainbackArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<0>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<1>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<2>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<3>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<4>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<5>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_launch_export<6>(const RegExportArgs&, unsigned, hipStream_t);
 
 inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t frames,
                       size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start,
@@ -774,7 +870,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     RegUpdateArgs a{};
     a.symbols = (const uint8_t*)d_symbols;
     a.sym_frame_stride_bytes = n_steps * (size_t)rc.R * (shift ? 1 : 2);
-    if (a.sym_frame_stride_bytes * 32 >= 0xFFFFFFFFull) return -2;   // per-lane 32-bit buffer offsets
+    if (a.sym_frame_stride_bytes * (size_t)rc.tile >= 0xFFFFFFFFull) return -2;   // per-lane 32-bit buffer offsets
     a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
     a.ws = (uint4*)d_ws;
     a.ws_tile_stride = reg_groups(rc, L) * 64;
@@ -784,13 +880,15 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     a.frames = (u32)frames;
     a.n_steps = (u32)n_steps;
     a.cfg = cfg;
-    const unsigned tiles = (unsigned)reg_tiles(frames);
+    const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     switch (rc.id) {
         case 0: return reg_launch_update<0>(shift, a, tiles, st);
         case 1: return reg_launch_update<1>(shift, a, tiles, st);
         case 2: return reg_launch_update<2>(shift, a, tiles, st);
         case 3: return reg_launch_update<3>(shift, a, tiles, st);
         case 4: return reg_launch_update<4>(shift, a, tiles, st);
+        case 5: return reg_launch_update<5>(shift, a, tiles, st);
+        case 6: return reg_launch_update<6>(shift, a, tiles, st);
         default: return -1;
     }
 }
@@ -805,13 +903,15 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.end_state = d_end;
     a.frames = (u32)frames;
     a.L = (u32)L;
-    const unsigned tiles = (unsigned)reg_tiles(frames);
+    const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     switch (rc.id) {
         case 0: return reg_launch_chainback<0>(a, tiles, st);
         case 1: return reg_launch_chainback<1>(a, tiles, st);
         case 2: return reg_launch_chainback<2>(a, tiles, st);
         case 3: return reg_launch_chainback<3>(a, tiles, st);
         case 4: return reg_launch_chainback<4>(a, tiles, st);
+        case 5: return reg_launch_chainback<5>(a, tiles, st);
+        case 6: return reg_launch_chainback<6>(a, tiles, st);
         default: return -1;
     }
 }
@@ -828,7 +928,12 @@ inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t
     const size_t W = rc.K == 9 ? 4 : 1;
     const size_t total = frames * n_steps * W;
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    return rc.K == 9 ? reg_launch_export<3>(a, blocks, st) : reg_launch_export<0>(a, blocks, st);
+    switch (rc.K) {
+        case 9: return reg_launch_export<3>(a, blocks, st);
+        case 3: return reg_launch_export<5>(a, blocks, st);
+        case 5: return reg_launch_export<6>(a, blocks, st);
+        default: return reg_launch_export<0>(a, blocks, st);
+    }
 }
 #endif  // VIT_REG_ID
 
