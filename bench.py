@@ -86,6 +86,15 @@ def cpu_baseline(code_id, code, pc, decode_type, sym_host, tx_host, L, target_se
 
 def main():
     args = parse()
+    if not os.path.exists(os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")):
+        # clean checkout: compile the HIP extension first (there is no other decode path to fall back to)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            while not os.path.exists(os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")):
+                time.sleep(1.0)
+            time.sleep(2.0)
     import numpy as np
     import torch
     import torch.distributed as dist

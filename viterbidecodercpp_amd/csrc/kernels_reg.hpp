@@ -1,14 +1,15 @@
-// kernels_reg.hpp -- PLAN_REG: state metrics resident in VGPRs, 4 lanes per frame PAIR, packed 2x16-bit arithmetic.
+// kernels_reg.hpp -- PLAN_REG: state metrics resident in VGPRs, packed 2x16-bit arithmetic, frames in pairs.
 //
-// Device implementation of the reference's scalar strategy for the K = 7 and K = 9 stock codes
+// Device implementation of the reference's scalar strategy for the K = 3, 5, 7, 9 stock codes
 //   ViterbiDecoder_Scalar::update / bfly / renormalise   include/viterbi/viterbi_decoder_scalar.h:29-153
 //   ViterbiDecoder_Core::chainback                       include/viterbi/viterbi_decoder_core.h:214-236
 // Results are bit-identical to PLAN_LDS and to the reference; only the mapping onto the machine differs.
 //
-// Mapping (gfx950, wave64).  One wavefront decodes a TILE of 32 frames.  Lane l = 16*q + g (q = 0..3, g = 0..15) works
-// on the frame pair (A = 32*tile + g, B = A + 16): every VGPR holds one state metric of frame A in its low half and the
-// same state's metric of frame B in its high half, so one v_pk_* instruction advances two frames.  The 2^(K-1) states of
-// a frame are spread over the 4 q-lanes x NREG registers: "slot" x = (q << REG_BITS) | r.
+// Mapping (gfx950, wave64), LANE_BITS = 2 (K = 7, 9).  One wavefront decodes a TILE of 32 frames.  Lane l = 16*q + g
+// (q = 0..3, g = 0..15) works on the frame pair (A = 32*tile + g, B = A + 16): every VGPR holds one state metric of frame A
+// in its low half and the same state's metric of frame B in its high half, so one v_pk_* instruction advances two frames.
+// The 2^(K-1) states of a frame are spread over the 4 q-lanes x NREG registers: "slot" x = (q << REG_BITS) | r.
+// LANE_BITS = 0 (K = 3, 5): all states of a pair sit in one lane (64 pairs = 128 frames per wave, no cross-lane traffic).
 //
 //   * in-place butterflies by index rotation: at trellis step t (phase ph = t mod (K-1)) state s lives in slot
 //     rotr^ph(s).  The butterfly {(0|X),(1|X)} -> {(X|0),(X|1)} then reads and writes the SAME two slots, which differ in
@@ -16,17 +17,22 @@
 //     lane bits, one v_permlane32_swap / v_permlane16_swap per register pair exchanges that lane bit with the top
 //     register bit before the butterflies and again after them (2 of every K-1 steps).
 //   * branch metrics: the convolutional code is linear, so the R-bit branch pattern of butterfly (q, r) is
-//     pat(r) ^ pat(q); pat(r) is a compile-time constant per register and pat(q) is folded in by swapping |high-y| and
-//     |low-y| per lane with a constant lane mask.  Only 2^R packed error sums E[p] (and max_error - E[p]) exist per step.
-//   * add-compare-select per register pair, exact for wrapping u16 metrics:  s = sat_sub(m_r0, m_r1) is non-zero iff
-//     m_r0 > m_r1 (the reference's strict '>' -- tie keeps r0), min = m_r0 - s, decision bit = min(s, 1).
+//     pat(r) ^ pat(q); pat(r) is a compile-time constant per register and pat(q) is folded in by giving every lane its own
+//     (phase, polynomial) copies of high/low.  Only 2^R packed error sums E[p] (and max_error - E[p]) exist per step, and
+//     those of step t+1 are computed inside step t's basic block (software pipelining).
+//   * add-compare-select per register pair, 8 packed instructions, exact for wrapping u16 metrics: metrics are kept
+//     biased (m ^ 0x8000) so the reference's unsigned compare is a signed one; new = v_pk_min_i16(x, y); the decision is
+//     the SIGN of v_pk_sub_i16(y, x) with clamp -- saturation keeps the sign exact at any distance, a tie gives 0 (the
+//     reference's strict '>' keeps predecessor 0).
 //   * u8 metrics / s8 symbols are carried in the HIGH byte of each 16-bit half, which makes 16-bit wrapping arithmetic
 //     reproduce mod-256 arithmetic.
-//   * decision bits: one dword per lane per 16 registers (frame A bits 0-15, frame B bits 16-31), stored as coalesced
-//     16-byte-per-lane rows: ws[tile][step group][lane] (1 KiB per wave store).  Bit order is the slot order of the step
+//   * decision bits: the sign bits of a lane's registers are byte-gathered (v_perm_b32 over the pair (r, r+8)) into one
+//     dword per 16 registers: byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B registers 8-15.  Stored as coalesced
+//     16-byte-per-lane rows ws[tile][step group][lane] (1 KiB per wave store).  Bit order is the slot order of the step
 //     (a rotation of the state index) -- vit_hip_export_decisions() converts to the reference's bit order.
-//   * chainback walks the same layout with the same lane roles: each q-lane extracts the candidate bit of its slice and a
-//     ds_bpermute fetches the one belonging to the survivor state.
+//   * chainback: K = 7 and K <= 5 use one lane per frame with everything on the dependent chain lane-local
+//     (reg_chainback16_kernel / reg_chainback0_kernel); K = 9 keeps the update kernel's lane roles, each q-lane extracts
+//     the candidate bit of its slice and a ds_bpermute fetches the survivor's (reg_chainback_kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,18 +56,8 @@ VIT_DEV u32 pk_add(u32 a, u32 b) {
 VIT_DEV u32 pk_sub(u32 a, u32 b) {
     return __builtin_bit_cast(u32, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b)));
 }
-VIT_DEV u32 pk_min_u(u32 a, u32 b) {
-    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
-}
 VIT_DEV u32 pk_max_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
-}
-// per-half unsigned saturating subtract.  Inline asm on purpose: hipcc's instcombine rewrites min(usub.sat(a,b),1) into
-// two scalar compares + selects + a byte permute, which is 3x the instructions.
-VIT_DEV u32 pk_sub_sat(u32 a, u32 b) {
-    u32 d;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
 }
 VIT_DEV u32 pk_min_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
@@ -70,12 +66,6 @@ VIT_DEV u32 pk_min_s(u32 a, u32 b) {
 VIT_DEV u32 pk_sub_sat_s(u32 a, u32 b) {
     u32 d;
     asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// d = lanemask[lane] ? b : a, lanemask a wave-uniform 64-bit constant
-VIT_DEV u32 cnd_mask(u32 a, u32 b, uint64_t lanemask) {
-    u32 d;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(lanemask));
     return d;
 }
 
