@@ -48,7 +48,9 @@ extern "C" {
 /* kernel plans (vit_hip_set_plan): which device implementation serves update()/chainback() */
 #define VIT_HIP_PLAN_AUTO 0
 #define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
-#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, 4 lanes per frame pair (K = 7, 9 stock codes)        */
+#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 3,4,5,7,9; R <= 4).
+                               The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
+                               an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, butterfly per thread, u32 metrics double-buffered in LDS
                                (K = 11..15, R <= 6, any polynomials)                                                  */
 
@@ -77,6 +79,7 @@ int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* br
                    int device, vit_hip_handle* out);
 int vit_hip_destroy(vit_hip_handle h);
 int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info);
+/* PLAN_AUTO never compiles anything: it resolves to a built-in plan (set VIT_HIP_JIT=1 before vit_hip_create to let it). */
 int vit_hip_set_plan(vit_hip_handle h, int plan);
 
 /* Opaque blob carrying everything vit_hip_create needs (header + table + config): the payload broadcast to the other

@@ -23,8 +23,8 @@ def test_plan_selection_and_errors():
         info = dec._handle.info
         assert list(info.polynomials[:COMMON_CODES[cid].R]) == list(COMMON_CODES[cid].G) and info.table_is_linear == 1
         assert (info.soft_decision_high, info.soft_decision_low) == (127, -127)
-    # K=7 with non-stock polynomials: served by the LDS plan, REG refused
-    code = Code("custom", 7, 2, (0o171, 0o133))
+    # K=6 has no register plan (and no LDS2): served by the LDS plan, the others refused
+    code = Code("custom", 6, 2, (0o65, 0o57))
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_LDS
@@ -133,3 +133,40 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
         torch.cuda.synchronize()
         want, _, _ = oracle.decode_frames(code.K, code.R, code.G, ocfg, sym, L, threads=4)
         assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("K,R,G,decode_type", [
+    (7, 2, (0o171, 0o133), "SOFT16"),        # the CCSDS/NASA pair written in the other polynomial order / bit order
+    (7, 3, (0o133, 0o171, 0o165), "HARD8"),
+    (9, 2, (0o557, 0o663), "SOFT16"),
+    (9, 3, (0o557, 0o663, 0o711), "SOFT8"),
+    (5, 3, (0o25, 0o33, 0o37), "SOFT16"),
+    (4, 2, (0o15, 0o17), "SOFT16"),
+    (3, 4, (0o5, 0o7, 0o7, 0o5), "HARD8"),
+])
+def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
+    """polynomials outside the ahead-of-time table: PLAN_REG is compiled for them on first use (reg_jit.hpp) and must
+    agree with the oracle exactly like the stock instantiations."""
+    code = Code(f"custom K{K}R{R}", K, R, tuple(G))
+    pc, table, config = make_table_config(code, decode_type)
+    assert BatchDecoder(table, config).plan == _lib.PLAN_LDS          # AUTO does not compile anything behind the caller's back
+    dec = check_batch_against_oracle(oracle, code, decode_type, 70, 384, 3.0, seed=K * R, plan=_lib.PLAN_REG)
+    assert dec.plan == _lib.PLAN_REG
+    rng = np.random.default_rng(K)
+    ss = rng.integers(0, code.num_states, 33).astype(np.int32)
+    es = rng.integers(0, code.num_states, 33).astype(np.int32)
+    check_batch_against_oracle(oracle, code, decode_type, 33, 104, 2.0, seed=K + R, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
+
+
+def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tmp_path):
+    lib = _lib.load()
+    monkeypatch.setenv("VIT_HIP_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("VIT_HIP_CACHE_DIR", str(tmp_path))
+    code = Code("custom", 7, 2, (0o147, 0o135))
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
+    msg = lib.vit_hip_last_error()
+    assert b"hipcc" in msg, msg
+    dec._handle.refresh()
+    assert dec.plan == _lib.PLAN_LDS                                  # still usable on the LDS plan

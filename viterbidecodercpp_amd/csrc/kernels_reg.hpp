@@ -177,7 +177,7 @@ VIT_DEV uint4 load_chunk(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 mis, bool fi
 }
 
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) {
+VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int SB = SP::SB, R = SP::R, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS, T = SP::T;
     constexpr int SBY = SHIFT ? 1 : 2;   // sizeof(soft_t)
     constexpr int BPS = R * SBY;         // symbol bytes per trellis step per frame
@@ -477,7 +477,7 @@ struct RegChainbackArgs {
 };
 
 template <class SP>
-__global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) {
+VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) {
 // (28 x 1 KiB loads in flight per wave); the main loop is branch-free so that hipcc can retire the ring with counted
 // s_waitcnt vmcnt(N) instead of draining it (a branch around a load costs a vmcnt(0)).
 template <class SP>
-__global__ void __launch_bounds__(64) reg_chainback16_kernel(RegChainbackArgs a) {
+VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     static_assert(SP::NREG == 16 && SP::DW == 1 && SP::SPS == 4 && SP::SB == 6, "K = 7 layout");
     constexpr int SB = SP::SB;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(64) reg_chainback16_kernel(RegChainbackArgs a)
 // The frame's pair-lane row (16 B per 4 steps) holds all of its decision bits; same register-ring / branch-free structure
 // as reg_chainback16_kernel.
 template <class SP>
-__global__ void __launch_bounds__(64) reg_chainback0_kernel(RegChainbackArgs a) {
+VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
     static_assert(SP::LANE_BITS == 0 && SP::NREG <= 16 && SP::DW == 1 && SP::SPS == 4, "small-K layout");
     constexpr int SB = SP::SB;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
@@ -724,7 +724,7 @@ struct RegExportArgs {
 };
 
 template <class SP>
-__global__ void reg_export_kernel(RegExportArgs a) {
+VIT_DEV void reg_export_body(const RegExportArgs& a) {
     constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
     constexpr int W = SB >= 6 ? 1 << (SB - 6) : 1;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (frame, step, word)
@@ -749,6 +749,25 @@ __global__ void reg_export_kernel(RegExportArgs a) {
     a.out[idx] = word;
 }
 
+// ---- kernels: thin __global__ wrappers (the bodies above are shared with the run-time compiled instantiations) --------
+template <class SP, int SHIFT>
+__global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT>(a); }
+
+// chainback: one kernel name per code, the body is picked by the code's geometry
+template <class SP>
+VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
+    if constexpr (SP::LANE_BITS == 0) reg_chainback0_body<SP>(a);
+    else if constexpr (SP::NREG == 16) reg_chainback16_body<SP>(a);
+    else reg_chainback_coop_body<SP>(a);
+}
+template <class SP>
+constexpr unsigned reg_chainback_frames_per_block() { return (SP::LANE_BITS == 0 || SP::NREG == 16) ? 64u : 32u; }
+template <class SP>
+__global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) { reg_chainback_body<SP>(a); }
+template <class SP>
+__global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
+
+#ifndef VIT_REG_JIT_TU
 // ---- host side ----------------------------------------------------------------------------------------------------
 using Spec_K7R2 = RegSpec<7, 2, 109, 79, 0, 0>;             // Voyager          (common_codes.h:23)
 using Spec_K7R3 = RegSpec<7, 3, 91, 117, 121, 0>;           // LTE              (:24)
@@ -758,10 +777,19 @@ using Spec_K9R4 = RegSpec<9, 4, 501, 441, 331, 315>;        // CDMA 2000        
 using Spec_K3R2 = RegSpec<3, 2, 7, 5, 0, 0, 0>;             // Basic K=3        (:21)  all 4 states in one lane
 using Spec_K5R2 = RegSpec<5, 2, 23, 25, 0, 0, 0>;           // Basic K=5        (:22)  all 16 states in one lane
 
+// a run-time compiled instantiation (reg_jit.hpp): the same four kernels for polynomials that are not in the table above
+struct RegJitModule {
+    hipModule_t module = nullptr;
+    hipFunction_t update[2] = {nullptr, nullptr};   // [0] 16-bit, [1] 8-bit metrics/symbols
+    hipFunction_t chainback = nullptr, export_ = nullptr;
+    unsigned chainback_frames_per_block = 32;
+};
+
 struct RegCode {
-    int id = -1;   // 0..6 in the order above
+    int id = -1;   // 0..6 in the order above; -1 with jit != nullptr for a run-time compiled code
     int K = 0, R = 0;
     int tile = 32; // frames per wavefront
+    const RegJitModule* jit = nullptr;
 };
 
 inline bool reg_code_supported(int K, int R) {
@@ -816,13 +844,8 @@ template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a,
 }
 template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
-    if constexpr (SP::LANE_BITS == 0) {
-        hipLaunchKernelGGL(reg_chainback0_kernel<SP>, dim3((a.frames + 63) / 64), dim3(64), 0, st, a);
-    } else if constexpr (SP::NREG == 16) {
-        hipLaunchKernelGGL(reg_chainback16_kernel<SP>, dim3((a.frames + 63) / 64), dim3(64), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
-    }
+    constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
+    hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
@@ -853,6 +876,12 @@ template <> int reg_launch_export<4>(const RegExportArgs&, unsigned, hipStream_t
 template <> int reg_launch_export<5>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<6>(const RegExportArgs&, unsigned, hipStream_t);
 
+inline int reg_jit_launch(hipFunction_t fn, const void* args, size_t args_bytes, unsigned grid, unsigned block, hipStream_t st) {
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_bytes,
+                      HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, st, nullptr, config) == hipSuccess ? 0 : -1;
+}
+
 inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t frames,
                       size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start,
                       hipStream_t st) {
@@ -871,6 +900,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     a.n_steps = (u32)n_steps;
     a.cfg = cfg;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
+    if (rc.jit) return reg_jit_launch(rc.jit->update[shift ? 1 : 0], &a, sizeof(a), tiles, 64, st);
     switch (rc.id) {
         case 0: return reg_launch_update<0>(shift, a, tiles, st);
         case 1: return reg_launch_update<1>(shift, a, tiles, st);
@@ -894,6 +924,10 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.frames = (u32)frames;
     a.L = (u32)L;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
+    if (rc.jit) {
+        const unsigned fpb = rc.jit->chainback_frames_per_block;
+        return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st);
+    }
     switch (rc.id) {
         case 0: return reg_launch_chainback<0>(a, tiles, st);
         case 1: return reg_launch_chainback<1>(a, tiles, st);
@@ -918,6 +952,7 @@ inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t
     const size_t W = rc.K == 9 ? 4 : 1;
     const size_t total = frames * n_steps * W;
     const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (rc.jit) return reg_jit_launch(rc.jit->export_, &a, sizeof(a), blocks, 256, st);
     switch (rc.K) {
         case 9: return reg_launch_export<3>(a, blocks, st);
         case 3: return reg_launch_export<5>(a, blocks, st);
@@ -926,5 +961,6 @@ inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t
     }
 }
 #endif  // VIT_REG_ID
+#endif  // VIT_REG_JIT_TU
 
 }  // namespace vit

@@ -14,6 +14,7 @@
 #include "kernels_lds.hpp"
 #include "kernels_lds2.hpp"
 #include "kernels_reg.hpp"
+#include "reg_jit.hpp"
 
 namespace {
 
@@ -155,6 +156,25 @@ int lds_chainback(vit_hip_handle h, const uint64_t* d_decisions, size_t frames, 
     return VIT_HIP_OK;
 }
 
+// run-time compiled PLAN_REG for polynomials outside the ahead-of-time table (reg_jit.hpp)
+bool try_reg_jit(vit_hip_handle h) {
+    if (h->reg_ok) return true;
+    if (!h->linear || !vit::reg_jit_supported(h->K, h->R)) return false;
+    std::string err;
+    const vit::RegJitModule* m = vit::reg_jit_get(h->K, h->R, h->G, h->device, err);
+    if (!m) {
+        g_last_error = err;
+        return false;
+    }
+    h->reg_code.id = -1;
+    h->reg_code.K = h->K;
+    h->reg_code.R = h->R;
+    h->reg_code.tile = h->K < 7 ? 128 : 32;
+    h->reg_code.jit = m;
+    h->reg_ok = true;
+    return true;
+}
+
 int ensure_scratch(vit_hip_handle h, size_t bytes) {
     if (bytes <= h->scratch_bytes) return VIT_HIP_OK;
     if (h->d_scratch) VIT_HIP_CHECK(hipFree(h->d_scratch));
@@ -262,6 +282,10 @@ int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* br
         return fail(VIT_HIP_ERR_RUNTIME, "device allocation failed in vit_hip_create");
     }
     h->reg_ok = h->linear && vit::reg_code_supported(K, R) && vit::reg_code_init(&h->reg_code, K, R, h->G, h->cfg);
+    if (!h->reg_ok && h->linear && vit::reg_jit_supported(K, R)) {
+        const char* e = getenv("VIT_HIP_JIT");
+        if (e && *e == '1') (void)try_reg_jit(h);   // opt-in at create time; vit_hip_set_plan(PLAN_REG) always tries
+    }
     h->lds2_ok = vit::lds2_supported(K, R);
     h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
     *out = h;
@@ -292,8 +316,13 @@ int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
 int vit_hip_set_plan(vit_hip_handle h, int plan) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
-    if (plan == VIT_HIP_PLAN_REG && !h->reg_ok)
-        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG serves only the register-resident instantiations (see kernels_reg.hpp)");
+    if (plan == VIT_HIP_PLAN_REG && !h->reg_ok) {
+        DeviceGuard guard(h->device);
+        g_last_error.clear();
+        if (!guard.ok || !try_reg_jit(h))
+            return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG not available for this code: " +
+                        (g_last_error.empty() ? std::string("K must be 3,4,5,7 or 9, R <= 4, linear branch table") : g_last_error));
+    }
     if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
         return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 11..15 with R <= 6 (see kernels_lds2.hpp)");
     if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG && plan != VIT_HIP_PLAN_LDS2)
