@@ -478,18 +478,22 @@ struct RegChainbackArgs {
 
 template <class SP>
 VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
-    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
+    // K = 9 (64 registers, one 16-byte row per lane per step): the update kernel's lane roles.  Every q-lane extracts the
+    // candidate bit of its slice, a ds_bpermute fetches the one of the slice that owns the survivor's slot.  Rows are
+    // fetched NBUF steps ahead into a register ring; the main loop is branch-free so the ring keeps counted vmcnt waits.
+    static_assert(SP::DW == 4 && SP::SPS == 1 && SP::SB == 8 && SP::LANE_BITS == 2, "K = 9 layout");
+    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
-    constexpr int PF = 8;                                      // decision rows fetched ahead of the dependent chain
+    constexpr int NBUF = 8;                                    // == SB: a byte completes at a fixed slot of the ring
 
     const int lane = threadIdx.x & 63;
     const u32 g = lane & 15, q = lane >> 4;
     const size_t tile = blockIdx.x;
     const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
     const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
-    const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;
-    const uint4* ws_tile = a.ws + tile * a.ws_tile_stride;
+    const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;   // surplus lanes: identical stores
+    const uint4* rows = a.ws + tile * a.ws_tile_stride + lane;      // row of step t = rows[t*64]
     const size_t out_stride = ((size_t)a.L + 7) / 8;
     uint8_t* outA = a.out + (size_t)fA * out_stride;
     uint8_t* outB = a.out + (size_t)fB * out_stride;
@@ -497,66 +501,53 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     u32 regA = (a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u) << SHIFT_STATE;
     u32 regB = (a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u) << SHIFT_STATE;
 
-    // rows are consumed from t = L-1 + SB down to SB; row group = t / SPS
-    const int t_hi = (int)a.L - 1 + SB;
-    const int grp_hi = t_hi / SPS, grp_lo = SB / SPS;
-    auto load_row = [&](int grp) -> uint4 {
-        return (grp >= grp_lo) ? ws_tile[(size_t)grp * 64 + lane] : make_uint4(0, 0, 0, 0);
-    };
-    uint4 cur[PF], nxt[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) cur[k] = load_row(grp_hi - k);
-
-    auto trace = [&](u32& reg, u32 w, int half, int ph1) __attribute__((always_inline)) {
+    auto trace = [&](u32& reg, const uint4& v, u32 half, u32 ph1) __attribute__((always_inline)) {
         const u32 state = reg >> SHIFT_STATE;
         const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
         const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
-        const u32 mine = (w >> SP::dec_bit(rs, (u32)half)) & 1u;                // candidate from this lane's slice
-        const u32 bit = (u32)__shfl((int)mine, (int)(qs * 16 + g));           // the slice that owns slot x
+        const u32 d = rs >> 4;                                                // dword = slot register / 16
+        const u32 w = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
+        const u32 mine = (w >> SP::dec_bit(rs, half)) & 1u;                  // candidate from this lane's slice
+        const u32 bit = (u32)__shfl((int)mine, (int)(qs * 16 + g));          // the slice that owns slot x
         reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
     };
+    auto emit = [&](u32 jb) __attribute__((always_inline)) {
+        if (q == 0) {
+            outA[jb] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
+            outB[jb] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+        }
+    };
+    auto slow_step = [&](int t) __attribute__((always_inline)) {
+        const uint4 v = rows[(size_t)t * 64];
+        const u32 ph1 = (u32)((t + 1) % SB);
+        trace(regA, v, 0u, ph1);
+        trace(regB, v, 1u, ph1);
+        const int j = t - SB;
+        if ((j & 7) == 0) emit((u32)j >> 3);
+    };
 
-    for (int gbase = grp_hi; gbase >= grp_lo; gbase -= PF) {
+    int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
+    while (t >= SB && (t & 7) != 7) slow_step(t--);             // down to a multiple-of-8 boundary
+    if (t >= SB && t - (NBUF - 1) >= SB) {
+        uint4 buf[NBUF];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) nxt[k] = load_row(gbase - PF - k);
+        for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(t - b) * 64];
+        for (; t - (NBUF - 1) >= SB; t -= NBUF) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int grp = gbase - k;
-            if (grp >= grp_lo) {
-#pragma unroll
-                for (int sidx = SPS - 1; sidx >= 0; --sidx) {
-                    const int t = grp * SPS + sidx;
-                    if (t <= t_hi && t >= SB) {
-                        const int j = t - SB;
-                        const int ph1 = (t + 1) % SB;
-                        if constexpr (DW == 4) {
-                            // dword = slot register index / 16 -- differs per frame, select before the shift
-                            const u32 stA = regA >> SHIFT_STATE, stB = regB >> SHIFT_STATE;
-                            const u32 xA = ((stA >> ph1) | (stA << (SB - ph1))) & SP::SMASK;
-                            const u32 xB = ((stB >> ph1) | (stB << (SB - ph1))) & SP::SMASK;
-                            const u32 dA = (xA & (NREG - 1)) >> 4, dB = (xB & (NREG - 1)) >> 4;
-                            const uint4 v = cur[k];
-                            const u32 wA = dA == 0 ? v.x : dA == 1 ? v.y : dA == 2 ? v.z : v.w;
-                            const u32 wB = dB == 0 ? v.x : dB == 1 ? v.y : dB == 2 ? v.z : v.w;
-                            trace(regA, wA, 0, ph1);
-                            trace(regB, wB, 1, ph1);
-                        } else {
-                            const uint4 v = cur[k];
-                            const u32 w = sidx == 0 ? v.x : sidx == 1 ? v.y : sidx == 2 ? v.z : v.w;
-                            trace(regA, w, 0, ph1);
-                            trace(regB, w, 1, ph1);
-                        }
-                        if ((j & 7) == 0 && q == 0) {
-                            if (validA) outA[j >> 3] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
-                            if (validB) outB[j >> 3] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
-                        }
-                    }
-                }
+            for (int b = 0; b < NBUF; ++b) {
+                // step t-b with t % 8 == 7: (t - b + 1) % 8 == (8 - b) % 8
+                constexpr int dummy = 0; (void)dummy;
+                const u32 ph1 = (u32)((NBUF - b) % NBUF);
+                trace(regA, buf[b], 0u, ph1);
+                trace(regB, buf[b], 1u, ph1);
+                if (b == NBUF - 1) emit((u32)(t - b - SB) >> 3);    // j = t-7-8 is a multiple of 8
+                const int nxt = t - b - NBUF;
+                buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-#pragma unroll
-        for (int k = 0; k < PF; ++k) cur[k] = nxt[k];
     }
+    while (t >= SB) slow_step(t--);
 }
 
 // ---- lane-local chainback for the 16-register codes (K = 7): one lane per frame, 64 frames (two tiles) per wave ------
