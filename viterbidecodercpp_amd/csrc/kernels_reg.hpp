@@ -59,6 +59,12 @@ VIT_DEV u32 pk_sub(u32 a, u32 b) {
 VIT_DEV u32 pk_max_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
 }
+// (a & mask) | c in one instruction (hipcc otherwise splits the shift-in chain of the decision gather into and + or/bitop3)
+VIT_DEV u32 and_or(u32 a, u32 mask, u32 c) {
+    u32 d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    return d;
+}
 VIT_DEV u32 pk_min_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
 }
@@ -375,8 +381,8 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                             constexpr int rr = decltype(rc)::value;
                             if constexpr (rr < NREG) return D[rr]; else return 0u;
                         };
-                        lo4 = (__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), HI_BYTES) & SIGNS) | (lo4 >> 1);
-                        hi4 = (__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), HI_BYTES) & SIGNS) | (hi4 >> 1);
+                        lo4 = and_or(__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), HI_BYTES), SIGNS, lo4 >> 1);
+                        hi4 = and_or(__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), HI_BYTES), SIGNS, hi4 >> 1);
                     });
                     acc[d] = (lo4 >> 4) | hi4;
                 });
