@@ -37,7 +37,13 @@ lines = [f"# rocprofv3 summary `{tag}`", "",
          "(scripts/profile.sh; the 2 warm-up launches are included in the averages).", ""]
 
 # ---- pass 1: kernel stats ----
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every run into the same directory: keep only the most recent file of a pass"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -57,7 +63,11 @@ if stats:
 # ---- PMC passes ----
 counters = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values per dispatch]
 meta = {}
-for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+pmc_files = []
+for pass_dir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if os.path.isdir(pass_dir):
+        pmc_files += newest(os.path.join(pass_dir, "*", "*_counter_collection.csv"))
+for path in pmc_files:
     for r in csv.DictReader(open(path)):
         if "vit::" not in r["Kernel_Name"]:
             continue
