@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline $*"
 run() { name=$1; shift; timeout 600 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 run trace --kernel-trace --stats
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE

@@ -33,7 +33,7 @@ def short(name):
 
 
 lines = [f"# rocprofv3 summary `{tag}`", "",
-         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline`",
          "(scripts/profile.sh; the 2 warm-up launches are included in the averages).", ""]
 
 # ---- pass 1: kernel stats ----
