@@ -170,3 +170,30 @@ def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tm
     assert b"hipcc" in msg, msg
     dec._handle.refresh()
     assert dec.plan == _lib.PLAN_LDS                                  # still usable on the LDS plan
+
+
+@pytest.mark.parametrize("code_id,decode_type,plans", [
+    (2, "SOFT16", [_lib.PLAN_REG, _lib.PLAN_LDS]), (2, "HARD8", [_lib.PLAN_REG, _lib.PLAN_LDS]),
+    (3, "SOFT8", [_lib.PLAN_REG, _lib.PLAN_LDS]), (5, "HARD8", [_lib.PLAN_REG]), (1, "SOFT8", [_lib.PLAN_REG]),
+    (7, "HARD8", [_lib.PLAN_LDS2]),
+])
+def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
+    """a caller may hand over a view into a larger buffer: the symbol pointer is then only element-aligned."""
+    import torch
+    from tests.helpers import oracle_cfg
+
+    code = COMMON_CODES[code_id]
+    pc, table, config = make_table_config(code, decode_type)
+    F, L = (3, 32) if code.K == 15 else (37, 120)
+    S = L + code.K - 1
+    _, sym = synth.make_frames_numpy(code, pc, F, L, 3.0 if code.K < 15 else -2.0, seed=code_id)
+    want, _, _ = oracle.decode_frames(code.K, code.R, code.G, oracle_cfg(decode_type, code.R), sym, L, threads=4)
+    flat = torch.from_numpy(sym.reshape(-1))
+    for off in (1, 2, 3):
+        big = torch.zeros(flat.numel() + 8, dtype=flat.dtype, device="cuda")
+        big[off:off + flat.numel()] = flat.cuda()
+        view = big[off:off + flat.numel()].view(F, S, code.R)
+        assert view.data_ptr() % 4 == (off * flat.element_size()) % 4
+        for plan in plans:
+            dec = BatchDecoder(table, config, plan=plan)
+            assert np.array_equal(dec.decode(view, L).cpu().numpy(), want), (off, plan)
