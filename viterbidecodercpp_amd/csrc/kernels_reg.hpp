@@ -193,6 +193,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int NP = 1 << R;
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
+    // this kernel is VALU-issue bound; the chainback of the previous batch may be co-resident on a second stream: let
+    // these waves win the issue arbitration, the (latency/HBM-bound) bit chase fills the gaps (+4 % on the overlapped step)
+    __builtin_amdgcn_s_setprio(2);
     constexpr int PAIRS = SP::PAIRS, TILE = SP::TILE;
     const int lane = threadIdx.x & 63;
     const u32 g = lane & (PAIRS - 1), q = SP::LANE_BITS ? lane >> 4 : 0;
