@@ -1,0 +1,66 @@
+// viterbi_hip/viterbi_decoder_hip_batch.h -- RAII wrapper over the batched C ABI (include/vit_hip.h): many independent
+// frames, buffers resident in HBM, explicit stream.  Built from the same host types as the single-frame drop-in
+// (ViterbiBranchTable, ViterbiDecoder_Config), so a program moves from
+//     for each frame: vitdec.reset(); Decoder::update(vitdec, ...); vitdec.chainback(...)      (examples/run_benchmark.cpp:268-281)
+// to one call per batch without touching how the code or the configuration is described.  No HIP header is needed here:
+// device pointers and the stream are passed as plain pointers; allocation stays with the caller.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../vit_hip.h"
+#include "viterbi_branch_table.h"
+#include "viterbi_decoder_config.h"
+
+template <size_t constraint_length, size_t code_rate, typename error_t, typename soft_t>
+class ViterbiDecoder_HIP_Batch {
+public:
+    static constexpr size_t K = constraint_length, R = code_rate;
+    static constexpr size_t NUMSTATES = size_t(1) << (K - 1);
+    using BranchTable = ViterbiBranchTable<K, R, soft_t>;
+    using Config = ViterbiDecoder_Config<error_t>;
+
+    ViterbiDecoder_HIP_Batch(const BranchTable& table, const Config& config, int device = 0) {
+        check(vit_hip_create(int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)), table.data(), &config, device, &m_hip),
+              "vit_hip_create");
+    }
+    ~ViterbiDecoder_HIP_Batch() { vit_hip_destroy(m_hip); }
+    ViterbiDecoder_HIP_Batch(const ViterbiDecoder_HIP_Batch&) = delete;
+    ViterbiDecoder_HIP_Batch& operator=(const ViterbiDecoder_HIP_Batch&) = delete;
+
+    // bytes of device workspace (256-byte aligned) the decision history of `frames` frames of `total_bits` bits needs
+    size_t workspace_bytes(size_t frames, size_t total_bits) const { return vit_hip_workspace_bytes(m_hip, frames, total_bits); }
+    static size_t symbols_per_frame(size_t total_bits) { return (total_bits + K - 1) * R; }
+
+    // reset -> update -> chainback for every frame; everything is enqueued on `stream` (a hipStream_t), nothing synchronises
+    void decode(const soft_t* d_symbols, size_t frames, size_t total_bits, void* d_workspace, size_t workspace_size,
+                uint8_t* d_bytes_out, error_t* d_final_metrics = nullptr, uint64_t* d_renorm_sum = nullptr,
+                const uint32_t* d_end_state = nullptr, void* stream = nullptr) {
+        check(vit_hip_decode_batch(m_hip, d_symbols, frames, total_bits, d_workspace, workspace_size, d_bytes_out,
+                                   d_final_metrics, d_renorm_sum, d_end_state, stream), "vit_hip_decode_batch");
+    }
+    // the two phases separately, as the reference times them (run_benchmark.cpp:272-281)
+    void update(const soft_t* d_symbols, size_t frames, size_t total_bits, void* d_workspace, size_t workspace_size,
+                error_t* d_final_metrics = nullptr, uint64_t* d_renorm_sum = nullptr, const uint32_t* d_start_state = nullptr,
+                void* stream = nullptr) {
+        check(vit_hip_update_batch(m_hip, d_symbols, frames, total_bits + K - 1, total_bits, d_workspace, workspace_size,
+                                   d_final_metrics, d_renorm_sum, d_start_state, stream), "vit_hip_update_batch");
+    }
+    void chainback(const void* d_workspace, size_t frames, size_t total_bits, uint8_t* d_bytes_out,
+                   const uint32_t* d_end_state = nullptr, void* stream = nullptr) {
+        check(vit_hip_chainback_batch(m_hip, d_workspace, frames, total_bits, d_bytes_out, d_end_state, stream),
+              "vit_hip_chainback_batch");
+    }
+    vit_hip_handle hip_handle() const { return m_hip; }
+
+private:
+    static void check(int rc, const char* what) {
+        if (rc != VIT_HIP_OK) {
+            fprintf(stderr, "viterbi_hip: %s failed (%d): %s\n", what, rc, vit_hip_last_error());
+            abort();
+        }
+    }
+    vit_hip_handle m_hip = nullptr;
+};

@@ -11,7 +11,7 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 
 
 def _ensure_built():
-    if not (os.path.exists(os.path.join(CPP, "run_simple_hip")) and os.path.exists(os.path.join(CPP, "run_tests_hip"))):
+    if not all(os.path.exists(os.path.join(CPP, n)) for n in ("run_simple_hip", "run_tests_hip", "run_batch_hip")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
         subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
 
@@ -21,6 +21,7 @@ def test_cpp_programs_build():
     subprocess.run(["make", "-q", "-C", CPP], check=False)
     assert os.access(os.path.join(CPP, "run_simple_hip"), os.X_OK)
     assert os.access(os.path.join(CPP, "run_tests_hip"), os.X_OK)
+    assert os.access(os.path.join(CPP, "run_batch_hip"), os.X_OK)
 
 
 @pytest.mark.gpu
@@ -39,3 +40,12 @@ def test_run_tests_hip_matrix():
     assert "FAIL" not in p.stdout
     last = p.stdout.strip().splitlines()[-1]
     assert last.startswith("PASSED ") and last.split()[1].split("/")[0] == last.split()[1].split("/")[1]
+
+
+@pytest.mark.gpu
+def test_run_batch_hip():
+    """batched route from C++ (ViterbiDecoder_HIP_Batch) vs the oracle and vs the single-frame drop-in."""
+    _ensure_built()
+    p = subprocess.run([os.path.join(CPP, "run_batch_hip")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "mismatching frames=0" in p.stdout and p.stdout.strip().endswith("PASS")
