@@ -68,6 +68,72 @@ __global__ void NAME(uint32_t* out, uint32_t seed) {                            
 #define A_CNDV(i)     "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define A_PKADD_S(i)  "v_pk_add_u16 %" #i ", %" #i ", s12\n"
 #define A_ADD16_S(i)  "v_add_u16 %" #i ", s12, %" #i "\n"
+
+#define A_PERMSGN(i)  "v_perm_b32 %" #i ", %" #i ", %8, s13\n"
+#define A_PERMV(i)    "v_perm_b32 %" #i ", %" #i ", %8, %8\n"
+#define A_ANDOR_S(i)  "v_and_or_b32 %" #i ", %8, s13, %" #i "\n"
+#define A_BFI_S(i)    "v_bfi_b32 %" #i ", s13, %8, %" #i "\n"
+#define A_OR3(i)      "v_or3_b32 %" #i ", %" #i ", %8, %8\n"
+#define A_LSHLADD(i)  "v_lshl_add_u32 %" #i ", %" #i ", 1, %8\n"
+#define A_CMP32(i)    "v_cmp_gt_u32 vcc, %" #i ", %8\n"
+#define A_CMPSDWA(i)  "v_cmp_gt_i16_sdwa vcc, %" #i ", %8 src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define A_CMPE64(i)   "v_cmp_gt_i16 s[14:15], %" #i ", %8\n"
+#define A_PKADD_OPSEL(i) "v_pk_add_u16 %" #i ", %" #i ", %8 op_sel:[0,1] op_sel_hi:[1,0]\n"
+#define A_PKASHR(i)   "v_pk_ashrrev_i16 %" #i ", 15, %" #i "\n"
+#define A_PKLSHR(i)   "v_pk_lshrrev_b16 %" #i ", 15, %" #i "\n"
+#define A_BPERM(i)    "ds_bpermute_b32 %" #i ", %8, %" #i "\ns_waitcnt lgkmcnt(0)\n"
+#define A_ADDLIT(i)   "v_add_u32 %" #i ", 0x12345, %" #i "\n"
+#define A_ANDLIT(i)   "v_and_b32 %" #i ", 0x80808080, %" #i "\n"
+#define A_OR32(i)     "v_or_b32 %" #i ", %" #i ", %8\n"
+#define A_SUB32(i)    "v_sub_u32 %" #i ", %" #i ", %8\n"
+#define A_MAX32(i)    "v_max_i32 %" #i ", %" #i ", %8\n"
+#define A_ASHR32(i)   "v_ashrrev_i32 %" #i ", 31, %" #i "\n"
+#define A_BFE(i)      "v_bfe_u32 %" #i ", %" #i ", 15, 1\n"
+#define A_MBCNT(i)    "v_mbcnt_lo_u32_b32 %" #i ", %8, %" #i "\n"
+#define A_XAD(i)      "v_xad_u32 %" #i ", %" #i ", %8, %8\n"
+#define A_ADDF32(i)   "v_add_f32 %" #i ", %" #i ", %8\n"
+#define A_MULF32(i)   "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define A_ADDF16(i)   "v_add_f16 %" #i ", %" #i ", %8\n"
+#define A_PKADDF16(i) "v_pk_add_f16 %" #i ", %" #i ", %8\n"
+#define A_PKMINF16(i) "v_pk_min_f16 %" #i ", %" #i ", %8\n"
+#define A_MED3(i)     "v_med3_i32 %" #i ", %" #i ", %8, %8\n"
+#define A_MIN3_32(i)  "v_min3_u32 %" #i ", %" #i ", %8, %8\n"
+#define A_SAD8(i)     "v_sad_u8 %" #i ", %" #i ", %8, %8\n"
+#define A_DOT4(i)     "v_dot4_u32_u8 %" #i ", %" #i ", %8, %" #i "\n"
+#define A_ADDCO(i)    "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+
+KERNEL(k_n_permsgn, A_PERMSGN)
+KERNEL(k_n_permv, A_PERMV)
+KERNEL(k_n_andor_s, A_ANDOR_S)
+KERNEL(k_n_bfi_s, A_BFI_S)
+KERNEL(k_n_or3, A_OR3)
+KERNEL(k_n_lshladd, A_LSHLADD)
+KERNEL(k_n_cmp32, A_CMP32)
+KERNEL(k_n_cmpsdwa, A_CMPSDWA)
+KERNEL(k_n_cmpe64, A_CMPE64)
+KERNEL(k_n_pkadd_opsel, A_PKADD_OPSEL)
+KERNEL(k_n_pkashr, A_PKASHR)
+KERNEL(k_n_pklshr, A_PKLSHR)
+KERNEL(k_n_bperm, A_BPERM)
+KERNEL(k_n_addlit, A_ADDLIT)
+KERNEL(k_n_andlit, A_ANDLIT)
+KERNEL(k_n_or32, A_OR32)
+KERNEL(k_n_sub32, A_SUB32)
+KERNEL(k_n_max32, A_MAX32)
+KERNEL(k_n_ashr32, A_ASHR32)
+KERNEL(k_n_bfe, A_BFE)
+KERNEL(k_n_mbcnt, A_MBCNT)
+KERNEL(k_n_xad, A_XAD)
+KERNEL(k_n_addf32, A_ADDF32)
+KERNEL(k_n_mulf32, A_MULF32)
+KERNEL(k_n_addf16, A_ADDF16)
+KERNEL(k_n_pkaddf16, A_PKADDF16)
+KERNEL(k_n_pkminf16, A_PKMINF16)
+KERNEL(k_n_med3, A_MED3)
+KERNEL(k_n_min3_32, A_MIN3_32)
+KERNEL(k_n_sad8, A_SAD8)
+KERNEL(k_n_dot4, A_DOT4)
+KERNEL(k_n_addco, A_ADDCO)
 KERNEL(k_cnds, A_CNDS)
 KERNEL(k_bfi, A_BFI)
 KERNEL(k_andor, A_ANDOR)
@@ -141,7 +207,40 @@ int main() {
         {"v_pk_min_i16", k_pkmini, 1}, {"v_lshrrev_b32 (vop2)", k_shr32, 1}, {"v_and_b32", k_and32, 1}, {"v_xor_b32", k_xor32, 1},
         {"v_sub_u16", k_sub16, 1}, {"v_max_i16", k_maxi16, 1}, {"v_mov_b32", k_mov, 1}, {"v_cmp_gt_u16 (vopc)", k_cmp16, 1},
         {"v_addc_co_u32", k_addc, 1}, {"v_alignbit_b32", k_alignbit, 1}, {"v_mov_b32_dpp", k_movdpp, 1}, {"v_add_u16_dpp", k_adddpp, 1},
-        {"v_pk_add_u16 sgpr", k_pkadds, 1}, {"v_add_u16 sgpr", k_add16s, 1}};
+        {"v_pk_add_u16 sgpr", k_pkadds, 1}, {"v_add_u16 sgpr", k_add16s, 1},
+        {"permsgn", k_n_permsgn, 1},
+        {"permv", k_n_permv, 1},
+        {"andor_s", k_n_andor_s, 1},
+        {"bfi_s", k_n_bfi_s, 1},
+        {"or3", k_n_or3, 1},
+        {"lshladd", k_n_lshladd, 1},
+        {"cmp32", k_n_cmp32, 1},
+        {"cmpsdwa", k_n_cmpsdwa, 1},
+        {"cmpe64", k_n_cmpe64, 1},
+        {"pkadd_opsel", k_n_pkadd_opsel, 1},
+        {"pkashr", k_n_pkashr, 1},
+        {"pklshr", k_n_pklshr, 1},
+        {"bperm", k_n_bperm, 1},
+        {"addlit", k_n_addlit, 1},
+        {"andlit", k_n_andlit, 1},
+        {"or32", k_n_or32, 1},
+        {"sub32", k_n_sub32, 1},
+        {"max32", k_n_max32, 1},
+        {"ashr32", k_n_ashr32, 1},
+        {"bfe", k_n_bfe, 1},
+        {"mbcnt", k_n_mbcnt, 1},
+        {"xad", k_n_xad, 1},
+        {"addf32", k_n_addf32, 1},
+        {"mulf32", k_n_mulf32, 1},
+        {"addf16", k_n_addf16, 1},
+        {"pkaddf16", k_n_pkaddf16, 1},
+        {"pkminf16", k_n_pkminf16, 1},
+        {"med3", k_n_med3, 1},
+        {"min3_32", k_n_min3_32, 1},
+        {"sad8", k_n_sad8, 1},
+        {"dot4", k_n_dot4, 1},
+        {"addco", k_n_addco, 1},
+    };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("%-26s %10s %10s %10s   (cycles per wave-instruction per SIMD at 2.4 GHz nominal)\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD");

@@ -368,26 +368,35 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 });
                 // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
                 const u32 need = (pk_sub_sat_s(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
-                // ---- gather the 2 x NREG sign bits: bytes 1 and 3 of the register pair (r, r+8) -> one dword per 16 registers:
-                //      byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B registers 8-15, register k at bit k%8 ----
-                constexpr u32 SIGNS = 0x80808080u;
-                constexpr u32 HI_BYTES = 0x07050301u;   // {D[r].b1, D[r].b3, D[r+8].b1, D[r+8].b3}
+                // ---- gather the 2 x NREG sign bits.  v_perm_b32 selectors 8..11 replicate the sign of a 16-bit half over a
+                //      whole byte, so one perm of the register pair (r, r+8) yields four CLEAN bytes (0x00 / 0xFF):
+                //      {A r, B r, A r+8, B r+8}; pair j then drops into bit j of every byte with a single v_and_or (no shift
+                //      chain).  One dword per 16 registers: byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B
+                //      registers 8-15, register k at bit k%8 ----
+                constexpr u32 SIGN_BYTES = 0x0b0a0908u;
                 u32 acc[DW];
                 static_for<DW>([&](auto dc) __attribute__((always_inline)) {
                     constexpr int d = decltype(dc)::value;
-                    // two independent 4-deep shift-in chains instead of one 8-deep
+                    auto dreg = [&](auto rc) __attribute__((always_inline)) -> u32 {   // fewer than 16 registers: K < 7
+                        constexpr int rr = decltype(rc)::value;
+                        if constexpr (rr < NREG) return D[rr]; else return 0u;
+                    };
+                    // two independent 4-deep chains instead of one 8-deep
                     u32 lo4 = 0, hi4 = 0;
                     static_for<4>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         constexpr int r = 16 * d + k;
-                        auto dreg = [&](auto rc) __attribute__((always_inline)) -> u32 {   // fewer than 16 registers: K < 7
-                            constexpr int rr = decltype(rc)::value;
-                            if constexpr (rr < NREG) return D[rr]; else return 0u;
-                        };
-                        lo4 = and_or(__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), HI_BYTES), SIGNS, lo4 >> 1);
-                        hi4 = and_or(__builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), HI_BYTES), SIGNS, hi4 >> 1);
+                        const u32 pl = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), SIGN_BYTES);
+                        const u32 ph = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), SIGN_BYTES);
+                        if constexpr (k == 0) {
+                            lo4 = pl & 0x01010101u;
+                            hi4 = ph & 0x10101010u;
+                        } else {
+                            lo4 = and_or(pl, 0x01010101u << k, lo4);
+                            hi4 = and_or(ph, 0x10101010u << k, hi4);
+                        }
                     });
-                    acc[d] = (lo4 >> 4) | hi4;
+                    acc[d] = lo4 | hi4;
                 });
                 if constexpr (LP && NREG == 16) {
                     // registers 0-7 / 8-15 (low / high half of the dword) belong to different lanes until the exchange is
