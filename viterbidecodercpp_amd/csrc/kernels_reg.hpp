@@ -165,6 +165,7 @@ struct RegUpdateArgs {
 };
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
+typedef int v2i32_t __attribute__((ext_vector_type(2)));
 // 16 bytes of a frame's symbol stream through a bounds-checked buffer descriptor: bytes at or beyond the end of the
 // caller's buffer read as zero in hardware (no branches, no over-read).  `voff` is dword aligned; when a frame does not
 // start on a dword (odd strides: R = 3 with 8-bit symbols) `fix` is set wave-wide and the 16 bytes are funnel-shifted
@@ -187,10 +188,21 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int SB = SP::SB, R = SP::R, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS, T = SP::T;
     constexpr int SBY = SHIFT ? 1 : 2;   // sizeof(soft_t)
     constexpr int BPS = R * SBY;         // symbol bytes per trellis step per frame
-    // unrolled block: whole phases, whole 16-byte symbol chunks, whole decision rows
-    constexpr int U = clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
-    constexpr int NCH = U * BPS / 16;
     constexpr int NP = 1 << R;
+    // LDSBM: the 4 q-lanes of a frame pair share the branch-metric work through LDS.  In every group of 4 trellis steps
+    // lane (q, g) loads only the symbols of step 4J+q of its pair, computes that step's 2^R sums E[p] / max_error - E[p]
+    // ONCE (with the unswapped high / low) and parks them in an LDS ring; every step each lane then fetches
+    // E[p ^ pat_lane(phase, q)] with one ds_read_b64 per pattern through per-lane addresses.  22 VALU per lane and step
+    // become 6 (+ 4 LDS reads that issue beside the other wave's VALU).
+    constexpr bool LDSBM = SP::LANE_BITS == 2 && R == 2;
+    constexpr int GROUP = 4;
+    // unrolled block: whole phases, whole decision rows, and whole 16-byte symbol chunks / whole 4-step groups
+    constexpr int U = LDSBM ? clcm(clcm(SB, GROUP), SPS) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
+    constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
+    constexpr int NG = U / GROUP;                 // groups per block == depth of the symbol register ring
+    constexpr int RING = U;                       // LDS ring, in steps: slot of step t = t % U is a compile-time constant
+    constexpr int ROW = NP * 16;                  // uint2 {E, EB} entries per step: [pattern][pair g]
+    __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
     // this kernel is VALU-issue bound; the chainback of the previous batch may be co-resident on a second stream: let
@@ -230,17 +242,37 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
 
     // the branch pattern contributed by this lane's group q is folded in by exchanging `high` and `low` per polynomial:
     // per-lane constants, one pair per (phase, polynomial)
-    u32 HIc[SB][R], LOc[SB][R];
-    static_for<SB>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int ph = decltype(pc)::value;
-        static_for<R>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            constexpr uint64_t LM = SP::lane_mask(ph, i);
-            const bool swapped = (LM >> lane) & 1ull;
-            HIc[ph][i] = swapped ? LOW2 : HIGH2;
-            LOc[ph][i] = swapped ? HIGH2 : LOW2;
+    u32 HIc[LDSBM ? 1 : SB][R], LOc[LDSBM ? 1 : SB][R];
+    if constexpr (!LDSBM) {
+        static_for<SB>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int ph = decltype(pc)::value;
+            static_for<R>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr uint64_t LM = SP::lane_mask(ph, i);
+                const bool swapped = (LM >> lane) & 1ull;
+                HIc[ph][i] = swapped ? LOW2 : HIGH2;
+                LOc[ph][i] = swapped ? HIGH2 : LOW2;
+            });
         });
-    });
+    }
+    // LDSBM: ring index (uint2 units) this lane READS pattern p from in phase ph: entry (p ^ pat_lane(ph, q)) of pair g;
+    // and the one it WRITES its own step of a group to (step 4J+q: row q of the group, pattern 0, pair g)
+    u32 rd_idx[LDSBM ? SB : 1][NP];
+    const u32 wr_idx = q * ROW + g;
+    if constexpr (LDSBM) {
+        static_for<SB>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int ph = decltype(pc)::value;
+            const u32 x = q == 0 ? SP::pat_lane(ph, 0) : q == 1 ? SP::pat_lane(ph, 1) : q == 2 ? SP::pat_lane(ph, 2) : SP::pat_lane(ph, 3);
+            static_for<NP>([&](auto ppc) __attribute__((always_inline)) {
+                constexpr u32 p = decltype(ppc)::value;
+                rd_idx[ph][p] = ((p ^ x) << 4) + g;
+            });
+        });
+    }
+    // LDSBM symbol fetch: the BPS bytes of step 4J+q sit at byte rawX + BPS*q + 4*BPS*J of the tile: an 8-byte load from
+    // the dword below and a per-lane v_alignbyte (4*BPS is a multiple of 4, so the shift is the same for every group)
+    const u32 gvA = (rawA + BPS * q) & ~3u, gsA = (rawA + BPS * q) & 3u;
+    const u32 gvB = (rawB + BPS * q) & ~3u, gsB = (rawB + BPS * q) & 3u;
 
     // ---- reset (viterbi_decoder_core.h:202-211): phase 0, slot == state ----
     u32 m[NREG];
@@ -256,12 +288,21 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         });
     }
 
-    uint4 cA[NCH], cB[NCH];
+    uint4 cA[NCH ? NCH : 1], cB[NCH ? NCH : 1];
     static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
         cA[c] = load_chunk(rsrc, offA + 16 * c, misA, fix);
         cB[c] = load_chunk(rsrc, offB + 16 * c, misB, fix);
     });
+    // LDSBM: symbols of this lane's step of the next NG groups (register ring, slot = group % NG)
+    u32 gA[NG][2], gB[NG][2];
+    auto load_group = [&](u32 first_step, auto slotc) __attribute__((always_inline)) {
+        constexpr int sl = decltype(slotc)::value;
+        const v2i32_t va = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvA + first_step * BPS), 0, 0);
+        const v2i32_t vb = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvB + first_step * BPS), 0, 0);
+        gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y;
+        gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y;
+    };
 
     uint64_t rsA = 0, rsB = 0;
     u32 dq[4] = {0, 0, 0, 0};
@@ -304,7 +345,56 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         });
     };
     static_assert(U % 2 == 0, "E double buffer alternates per step");
-    branch_metrics(std::integral_constant<int, 0>{});
+    // LDSBM producer: this lane's step of the group whose first step has ring slot `slot0`, from symbol ring slot `sl`
+    auto bm_produce = [&](auto slot0c, auto slc) __attribute__((always_inline)) {
+        constexpr int slot0 = decltype(slot0c)::value, sl = decltype(slc)::value;
+        const u32 wa = __builtin_amdgcn_alignbyte(gA[sl][1], gA[sl][0], gsA);
+        const u32 wb = __builtin_amdgcn_alignbyte(gB[sl][1], gB[sl][0], gsB);
+        u32 A1[R], A0[R];
+        static_for<R>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int sub = i * SBY;
+            constexpr u32 sel = SHIFT ? (0x0cu | ((u32)sub << 8) | (0x0cu << 16) | ((u32)(4 + sub) << 24))
+                                      : ((u32)sub | ((u32)(sub + 1) << 8) | ((u32)(4 + sub) << 16) | ((u32)(5 + sub) << 24));
+            const u32 Y = __builtin_amdgcn_perm(wb, wa, sel);
+            const u32 d1 = pk_sub(HIGH2, Y), d0 = pk_sub(LOW2, Y);
+            A1[i] = pk_max_s(d1, pk_sub(0u, d1));
+            A0[i] = pk_max_s(d0, pk_sub(0u, d0));
+        });
+        static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            u32 e = (p & 1) ? A1[0] : A0[0];
+            static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value + 1;
+                e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
+            });
+            bm_ring[wr_idx + slot0 * ROW + p * 16] = make_uint2(e, pk_sub(MAXE2, e));
+        });
+        // one wavefront per workgroup: LDS operations of a wave complete in order, so the other lanes' reads that follow
+        // in program order see these rows; the fence only keeps the compiler from moving them across
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // LDSBM consumer: this lane's view of block step `un` (un == U: step 0 of the next block)
+    auto bm_fetch = [&](auto unc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value;
+        constexpr int us = un % U, PHn = us % SB, buf = un & 1;
+        static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const uint2 v = bm_ring[rd_idx[PHn][p] + us * ROW];
+            E[buf][p] = v.x;
+            EB[buf][p] = v.y;
+        });
+    };
+    if constexpr (LDSBM) {
+        static_for<NG>([&](auto sc) __attribute__((always_inline)) { load_group((u32)(decltype(sc)::value * GROUP), sc); });
+        bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        load_group((u32)(NG * GROUP), std::integral_constant<int, 0>{});
+        bm_fetch(std::integral_constant<int, 0>{});
+    } else {
+        branch_metrics(std::integral_constant<int, 0>{});
+    }
 
     u32 t0 = 0;
     // one unrolled block of U trellis steps; `guarded` adds the per-step bound check needed only by the last, partial block
@@ -315,7 +405,18 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             constexpr int PH = u % SB;
             constexpr int cur = u & 1;
             if (!GUARDED || t0 + u < a.n_steps) {
-                branch_metrics(std::integral_constant<int, u + 1>{});
+                if constexpr (LDSBM) {
+                    if constexpr (u % GROUP == 0) {
+                        // first step of block group Jb: produce group Jb + 1, then refill its symbol slot with group Jb + 1 + NG
+                        constexpr int Jb = u / GROUP;
+                        constexpr int sl = (Jb + 1) % NG;
+                        bm_produce(std::integral_constant<int, (GROUP * (Jb + 1)) % RING>{}, std::integral_constant<int, sl>{});
+                        load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
+                    }
+                    bm_fetch(std::integral_constant<int, u + 1>{});
+                } else {
+                    branch_metrics(std::integral_constant<int, u + 1>{});
+                }
                 // ---- refill the symbol chunks whose last reader was that look-ahead (next needed ~U steps from now) ----
                 static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
