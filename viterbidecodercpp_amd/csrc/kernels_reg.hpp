@@ -669,12 +669,14 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     while (t >= SB) slow_step(t--);
 }
 
-// ---- lane-local chainback for the 16-register codes (K = 7): one lane per frame, 64 frames (two tiles) per wave ------
+// ---- lane-local chainback for the 16-register codes (K = 7): one lane per frame PAIR, 64 pairs (four tiles) per wave ----
 // Nothing on the dependent bit-chase leaves the lane: the four q-rows of a step (16 B each, 4 steps per row) are all loaded
-// by the frame's lane, two v_perm pick this frame's bytes into a 64-bit word whose bit index IS the slot index, and the
-// survivor's bit is one shift away.  Rows are fetched NBUF groups (4 steps each) ahead of the chase into a register ring
-// (28 x 1 KiB loads in flight per wave); the main loop is branch-free so that hipcc can retire the ring with counted
-// s_waitcnt vmcnt(N) instead of draining it (a branch around a load costs a vmcnt(0)).
+// by the pair's lane, and every loaded byte is used (byte 0/2 of a dword = frame A, byte 1/3 = frame B; a lane per FRAME
+// loaded each row twice, and the kernel ran at the L1 delivery rate of ~12 B/clk/CU, not at HBM's).  Per frame two v_perm
+// pick its bytes into a 64-bit word whose bit index IS the slot index, and the survivor's bit is one shift away; the two
+// chases of a lane are independent, which hides their dependent latency.  Rows are fetched NBUF groups (4 steps each) ahead
+// into a register ring (28 x 1 KiB loads in flight per wave); the main loop is branch-free so that hipcc can retire the ring
+// with counted s_waitcnt vmcnt(N) instead of draining it (a branch around a load costs a vmcnt(0)).
 template <class SP>
 VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     static_assert(SP::NREG == 16 && SP::DW == 1 && SP::SPS == 4 && SP::SB == 6, "K = 7 layout");
@@ -684,29 +686,38 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     constexpr int NBUF = 8;                                    // even: keeps the byte-output positions compile-time
 
     const int lane = threadIdx.x & 63;
-    const u32 f_raw = blockIdx.x * 64 + lane;
-    const bool valid = f_raw < a.frames;
-    const u32 f = valid ? f_raw : a.frames - 1;                // surplus lanes redo the last frame (identical stores)
-    const u32 tile = f >> 5, g = f & 15u, half = (f >> 4) & 1u;
+    const u32 n_tiles = (a.frames + 31u) >> 5;
+    const u32 p_raw = blockIdx.x * 64 + lane;                  // frame pair (tile, g): frames 32*tile + g and + 16
+    const u32 tile = (p_raw >> 4) < n_tiles ? (p_raw >> 4) : n_tiles - 1, g = p_raw & 15u;
+    // surplus lanes / frames redo the last frame: the update kernel filled their half with that frame's decisions, so the
+    // stores are identical
+    const u32 fA = tile * 32u + g < a.frames ? tile * 32u + g : a.frames - 1;
+    const u32 fB = tile * 32u + g + 16u < a.frames ? tile * 32u + g + 16u : a.frames - 1;
     const uint4* rows = a.ws + (size_t)tile * a.ws_tile_stride + g;   // row (group, q) = rows[group*64 + q*16]
     const size_t out_stride = ((size_t)a.L + 7) / 8;
-    uint8_t* out = a.out + (size_t)f * out_stride;
-    // {row q.byte(h), row q.byte(2+h), row q+1.byte(h), row q+1.byte(2+h)}: this frame's 16+16 bits of two q-rows
-    const u32 selh = half | ((2u + half) << 8) | ((4u + half) << 16) | ((6u + half) << 24);
+    uint8_t* outA = a.out + (size_t)fA * out_stride;
+    uint8_t* outB = a.out + (size_t)fB * out_stride;
+    // {row q.byte(h), row q.byte(2+h), row q+1.byte(h), row q+1.byte(2+h)}: frame h's 16+16 bits of two q-rows
+    constexpr u32 SELA = 0x06040200u, SELB = 0x07050301u;
 
-    u32 reg = (a.end_state ? (a.end_state[f] & SP::SMASK) : 0u) << SHIFT_STATE;
+    u32 regA = (a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u) << SHIFT_STATE;
+    u32 regB = (a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u) << SHIFT_STATE;
 
-    // one traceback step on the four dwords (one per q-row) that hold step t
-    auto chase = [&](u32 d0, u32 d1, u32 d2, u32 d3, u32 ph1) __attribute__((always_inline)) {
-        const u32 lo = __builtin_amdgcn_perm(d1, d0, selh), hi = __builtin_amdgcn_perm(d3, d2, selh);
+    // one traceback step of one frame on the four dwords (one per q-row) that hold step t
+    auto chase1 = [&](u32& reg, u32 lo, u32 hi, u32 ph1) __attribute__((always_inline)) {
         const u32 state = reg >> SHIFT_STATE;
         const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
         const u32 w = (x & 32u) ? hi : lo;
         const u32 bit = (w >> (x & 31u)) & 1u;
         reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
     };
+    auto chase = [&](u32 d0, u32 d1, u32 d2, u32 d3, u32 ph1) __attribute__((always_inline)) {
+        chase1(regA, __builtin_amdgcn_perm(d1, d0, SELA), __builtin_amdgcn_perm(d3, d2, SELA), ph1);
+        chase1(regB, __builtin_amdgcn_perm(d1, d0, SELB), __builtin_amdgcn_perm(d3, d2, SELB), ph1);
+    };
     auto emit = [&](u32 jb) __attribute__((always_inline)) {    // byte jb is complete
-        out[jb] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+        outA[jb] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
+        outB[jb] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
     };
     // ragged ends: load the step's dwords directly (dependent latency, only a handful of steps)
     auto slow_step = [&](int t) __attribute__((always_inline)) {
@@ -729,27 +740,56 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
             for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(g_top - b) * 64 + qq * 16];
         int gb = g_top;
         u32 ph = (u32)((4 * gb + 3 + 1) % SB);                  // (t+1) % SB of the first step of the ring
-        for (; gb - (NBUF - 1) >= g_min; gb -= NBUF) {
+        // One inner iteration = NBUF groups = 32 steps = 4 output bytes per frame.  Inside the inner loop ONLY loads are
+        // outstanding: with a store pending next to them hipcc must assume out-of-order completion and drains the ring with
+        // s_waitcnt vmcnt(0) at every loop top (one full memory round trip per 32 steps -- that, not bandwidth, was the
+        // kernel's 1.16 ms).  The 4 bytes are assembled in a register, parked in LDS (lgkmcnt) and flushed as one
+        // (possibly unaligned) dword store per frame every KI iterations.
+        constexpr int KI = 32;
+        __shared__ uint2 obuf[KI * 64];
+        typedef u32 u32_unaligned __attribute__((aligned(1)));
+        while (gb - (NBUF - 1) >= g_min) {
+            // retire the previous flush (and the ring): the inner loop then starts with nothing but its own loads in flight
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            const int gb0 = gb;
+            int it = 0;
+            for (; it < KI && gb - (NBUF - 1) >= g_min; ++it, gb -= NBUF) {
+                u32 accA = 0, accB = 0;
 #pragma unroll
-            for (int b = 0; b < NBUF; ++b) {
-                const int grp = gb - b;                         // parity == parity of b (gb is even)
+                for (int b = 0; b < NBUF; ++b) {
+                    const int grp = gb - b;                     // parity == parity of b (gb is even)
 #pragma unroll
-                for (int sidx = 3; sidx >= 0; --sidx) {
-                    const u32 d0 = sidx == 0 ? buf[b][0].x : sidx == 1 ? buf[b][0].y : sidx == 2 ? buf[b][0].z : buf[b][0].w;
-                    const u32 d1 = sidx == 0 ? buf[b][1].x : sidx == 1 ? buf[b][1].y : sidx == 2 ? buf[b][1].z : buf[b][1].w;
-                    const u32 d2 = sidx == 0 ? buf[b][2].x : sidx == 1 ? buf[b][2].y : sidx == 2 ? buf[b][2].z : buf[b][2].w;
-                    const u32 d3 = sidx == 0 ? buf[b][3].x : sidx == 1 ? buf[b][3].y : sidx == 2 ? buf[b][3].z : buf[b][3].w;
-                    chase(d0, d1, d2, d3, ph);
-                    ph = ph == 0 ? SB - 1 : ph - 1;
-                    // j = 4*grp + sidx - 6 is a multiple of 8  <=>  grp odd and sidx == 2.  Unconditional byte store: a
-                    // branch (or a dword accumulator with a data-dependent flush) here would cost the ring its counted waits
-                    if ((b & 1) == 1 && sidx == 2) out[(u32)(4 * grp + sidx - SB) >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+                    for (int sidx = 3; sidx >= 0; --sidx) {
+                        const u32 d0 = sidx == 0 ? buf[b][0].x : sidx == 1 ? buf[b][0].y : sidx == 2 ? buf[b][0].z : buf[b][0].w;
+                        const u32 d1 = sidx == 0 ? buf[b][1].x : sidx == 1 ? buf[b][1].y : sidx == 2 ? buf[b][1].z : buf[b][1].w;
+                        const u32 d2 = sidx == 0 ? buf[b][2].x : sidx == 1 ? buf[b][2].y : sidx == 2 ? buf[b][2].z : buf[b][2].w;
+                        const u32 d3 = sidx == 0 ? buf[b][3].x : sidx == 1 ? buf[b][3].y : sidx == 2 ? buf[b][3].z : buf[b][3].w;
+                        chase(d0, d1, d2, d3, ph);
+                        ph = ph == 0 ? SB - 1 : ph - 1;
+                        // j = 4*grp + sidx - 6 is a multiple of 8  <=>  grp odd and sidx == 2: byte (4*grp - 4) / 8 is
+                        // complete; bytes come out in descending order, so the first one ends up in the top byte
+                        if ((b & 1) == 1 && sidx == 2) {
+                            accA = (accA << 8) | ((regA >> SHIFT_TAIL) & 0xFFu);
+                            accB = (accB << 8) | ((regB >> SHIFT_TAIL) & 0xFFu);
+                        }
+                    }
+                    // pin the chase of this group in front of its refill: without a side effect per group the optimiser sinks
+                    // the whole dependent chain below all eight refills and parks 128 permuted words in AGPRs / scratch
+                    asm volatile("" : "+v"(regA), "+v"(regB) : : "memory");
+                    const int nxt = grp - NBUF;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16];
+                    // keep the refill where it is written: hipcc otherwise sinks/merges the loads and the ring loses its depth
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                const int nxt = grp - NBUF;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16];
-                // keep the refill where it is written: hipcc otherwise sinks/merges the loads and the ring loses its depth
-                __builtin_amdgcn_sched_barrier(0);
+                obuf[it * 64 + lane] = make_uint2(accA, accB);
+            }
+            // iteration i started at group gb0 - NBUF*i (even) and completed bytes (gb0 - NBUF*i)/2 - 4 ... + 3
+            for (int i = 0; i < it; ++i) {
+                const uint2 v = obuf[i * 64 + lane];
+                const u32 jb = (u32)((gb0 - NBUF * i) / 2 - 4);
+                *(u32_unaligned*)(outA + jb) = v.x;
+                *(u32_unaligned*)(outB + jb) = v.y;
             }
         }
         t = 4 * gb + 3;
@@ -758,9 +798,6 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     while (t >= SB) slow_step(t--);
 }
 
-// ---- chainback for the small-K codes (LANE_BITS == 0): one lane per frame, 64 frames (half a tile) per wave -----------
-// The frame's pair-lane row (16 B per 4 steps) holds all of its decision bits; same register-ring / branch-free structure
-// as reg_chainback16_kernel.
 template <class SP>
 VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
     static_assert(SP::LANE_BITS == 0 && SP::NREG <= 16 && SP::DW == 1 && SP::SPS == 4, "small-K layout");
@@ -871,9 +908,9 @@ VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
     else reg_chainback_coop_body<SP>(a);
 }
 template <class SP>
-constexpr unsigned reg_chainback_frames_per_block() { return (SP::LANE_BITS == 0 || SP::NREG == 16) ? 64u : 32u; }
+constexpr unsigned reg_chainback_frames_per_block() { return SP::NREG == 16 && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
 template <class SP>
-__global__ void __launch_bounds__(64) reg_chainback_kernel(RegChainbackArgs a) { reg_chainback_body<SP>(a); }
+__global__ void __launch_bounds__(64, 2) reg_chainback_kernel(RegChainbackArgs a) { reg_chainback_body<SP>(a); }
 template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 

@@ -128,7 +128,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
         delete m;
         return nullptr;
     }
-    m->chainback_frames_per_block = (lane_bits == 0 || K == 7) ? 64u : 32u;
+    m->chainback_frames_per_block = K == 7 ? 128u : lane_bits == 0 ? 64u : 32u;
     modules()[mkey] = m;
     return m;
 }
