@@ -90,3 +90,46 @@ def test_out_of_range_symbols_wrap(oracle, plan, decode_type):
     else:
         sym = rng.integers(-128, 128, size=(F, S, code.R)).astype(np.int8)
     check_batch_against_oracle(oracle, code, decode_type, F, L, None, seed=0, plan=plan, sym=sym)
+
+
+def test_lds2_block_boundaries_and_mid_block_renormalisation(oracle):
+    """PLAN_LDS2 runs four trellis steps per barrier.  Cover every length of the last partial block (n_steps % 4, including
+    frames shorter than one block) and renormalisations that fall after the 1st, 2nd, 3rd and 4th step of a block: with a
+    threshold a little above the initial metrics state 0 reaches it every few steps, at drifting block positions."""
+    import torch
+    from oracle import pyoracle
+    from viterbidecodercpp_amd import BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config
+
+    code = Code("K11R2", 11, 2, (0o3345, 0o3613))
+    # (a) stock configuration, partial updates of 1..9 steps and whole frames with S % 4 = 0, 1, 2, 3
+    for n in range(1, 10):
+        check_batch_against_oracle(oracle, code, "SOFT16", 3, 64, 2.0, seed=n, plan=_lib.PLAN_LDS2, n_steps=n)
+    for L in (8, 16, 24, 32, 40, 48):   # S = L + 10
+        check_batch_against_oracle(oracle, code, "SOFT16", 5, L, 1.0, seed=L, plan=_lib.PLAN_LDS2)
+    # (b) frequent renormalisation at every block position, both widths
+    rng = np.random.default_rng(2024)
+    for width, thr_list in ((2, (700, 1100, 2500, 6000)), (1, (20, 33, 47, 90))):
+        sdt = np.int16 if width == 2 else np.int8
+        high, low = (127, -127) if width == 2 else (3, -3)
+        max_error = (high - low) * code.R
+        for thr in thr_list:
+            cfg = pyoracle.DecodeConfig(width, width, high, low, max_error, 0, max_error * (3 if width == 2 else 1), thr)
+            table = ViterbiBranchTable(code.K, code.R, code.G, cfg.high, cfg.low, sdt)
+            config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
+                                           cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
+            F, L = 3, 120 + int(rng.integers(0, 4))
+            S = L + code.K - 1
+            sym = rng.integers(low, high + 1, size=(F, S, code.R)).astype(sdt)
+            want = [oracle.decode(code.K, code.R, code.G, cfg, sym[f], L) for f in range(F)]
+            assert min(w["renorm_sum"] for w in want) > 0, "the case must renormalise"
+            dec = BatchDecoder(table, config, plan=_lib.PLAN_LDS2)
+            met, rs = dec.update(torch.from_numpy(sym).cuda(), L)
+            got_dec = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
+            out = dec.chainback(F, L).cpu().numpy()
+            met = met.cpu().numpy()
+            met = met.view(np.uint16) if width == 2 else met
+            for f in range(F):
+                assert np.array_equal(got_dec[f], want[f]["decisions"]), (width, thr, f)
+                assert np.array_equal(met[f].astype(np.uint32), want[f]["metrics"]), (width, thr, f)
+                assert int(rs[f].item()) == want[f]["renorm_sum"], (width, thr, f)
+                assert np.array_equal(out[f], want[f]["bytes"]), (width, thr, f)

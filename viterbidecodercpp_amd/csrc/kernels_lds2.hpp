@@ -1,31 +1,38 @@
 // kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 11..15, any polynomials): one workgroup per frame PAIR,
-// state metrics of both frames packed in one u32 per state and double-buffered in LDS, one thread per 8 butterflies.
+// state metrics of both frames packed in one u32 per state and double-buffered in LDS, FOUR trellis steps per barrier.
 //
 // Device implementation of the reference's scalar strategy
 //   ViterbiDecoder_Scalar::update / bfly / renormalise   include/viterbi/viterbi_decoder_scalar.h:29-153
 //   ViterbiDecoder_Core::chainback                       include/viterbi/viterbi_decoder_core.h:214-236
 // bit-identical to PLAN_LDS; this is the plan that makes K = 15 (Cassini, 16384 states) worth running on the GPU.
 //
-// Mapping (gfx950, wave64), N = 2^(K-1) states, H = N/2 butterflies, T = H/8 threads (1024 at K = 15):
-//   * LDS: old[N] and new[N] as u32 = (frame A metric | frame B metric << 16), both biased by 0x8000 so that the
-//     reference's unsigned compare is a SIGNED compare here (2 x 64 KiB at K = 15), plus a ring of per-step branch-metric
-//     tables.  Natural state order: butterfly j reads old[j], old[j+H] (lane-consecutive dwords: conflict free) and writes
-//     new[2j], new[2j+1] as ONE 8-byte store (lane-consecutive: conflict free).
-//   * thread `tid` owns butterflies j = tid + T*k, k = 0..7, for the whole frame, so its 8 branch patterns are loop
-//     invariant registers; per step it needs only {E[p], max_error - E[p]} for those patterns: one ds_read_b64 each from the
-//     step's 64-entry table.
-//   * the table of step t+NW is built during step t by wavefront (t mod NW) -- lane p computes entry p from the 2R symbols
-//     of the two frames -- so every wavefront pays for one table per NW steps and the table is ready long before it is read.
+// Mapping (gfx950, wave64), N = 2^(K-1) states, T = N/16 threads (1024 at K = 15), JB = K-5 bits of thread index j:
+//   * LDS: two metric buffers of N u32 = (frame A metric | frame B metric << 16), both biased by 0x8000 so that the
+//     reference's unsigned compare is a SIGNED compare here (2 x 64 KiB at K = 15), plus two sets of four 64-entry
+//     branch-metric tables {E[p], max_error - E[p]}.
+//   * radix-16 block: thread j loads the 16 states [r | j] (r = 0..15 in the TOP four index bits: lane-consecutive dwords,
+//     conflict free) and runs FOUR trellis steps on them in registers.  Stage c pairs the registers that differ in bit 3-c
+//     (their states differ in the top bit: a butterfly) and writes the two results back in place, so after stage c
+//     register r = (r3 r2 r1 r0) holds state [r(2-c)..r0 | j | r3..r(3-c)]; after stage 3 that is 16 j + r: the thread
+//     stores its 16 new metrics as four ds_write_b128.  One workgroup barrier and one pass over the metric buffers per
+//     FOUR steps (the one-step-per-barrier version spent 57 % of its cycles waiting).
+//   * the 4 x 8 branch patterns of a thread are loop invariant: LDS byte offsets into the step's table, one ds_read_b64 per
+//     butterfly.  The four tables of block b+1 are built during block b (wavefront c builds step c; lane p makes entry p).
 //   * add-compare-select in packed 16-bit, exact for wrapping metrics: min = v_pk_min_i16, decision = sign of the signed
 //     SATURATING difference (strict '>' of the reference: a tie keeps predecessor 0).
-//   * decisions: sign bits of the thread's 16 new states are byte-gathered into one dword (frame A in bytes 0/2, frame B in
-//     bytes 1/3) and stored ws[pair][step][tid]: 4 KiB contiguous per step.  vit_hip_export_decisions() converts to the
-//     reference bit order; lds2_chainback_kernel walks this layout directly.
-//   * one workgroup barrier per trellis step (metrics double buffer); renormalisation is a block-uniform rare branch:
-//     packed min over registers -> wave __shfl_xor scan -> LDS exchange between wavefronts.
+//   * decisions: the sign bits of the thread's 16 registers are byte-gathered into one dword per step (frame A in bytes
+//     0/2, frame B in bytes 1/3) and stored ws[pair][step][j]: 4 KiB contiguous per step.  lds2_locate() maps
+//     (step, state) -> (thread, register); vit_hip_export_decisions() converts to the reference bit order.
+//   * renormalisation (new_metric[0] >= threshold, scalar.h:48) after the LAST step of a block is the block-uniform rare
+//     branch it always was (min over registers -> wave scan -> LDS exchange).  After one of the first three steps only
+//     thread 0 can see it (state 0 sits in its register 0): it raises a flag, and behind the barrier the whole workgroup
+//     re-runs that block stage by stage with the reduction in between (about once per 1000 steps).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -45,6 +52,15 @@ VIT_L2 u32 l2_sub_sat_s(u32 a, u32 b) {
     asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+VIT_L2 u32 l2_and_or(u32 a, u32 mask, u32 c) {
+    u32 d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    return d;
+}
+template <class F, int... Is>
+VIT_L2 void l2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+VIT_L2 void l2_static_for(F&& f) { l2_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct Lds2UpdateArgs {
     const uint8_t* symbols;          // [F][n_steps][R] soft_t
@@ -60,27 +76,40 @@ struct Lds2UpdateArgs {
     DevConfig cfg;
 };
 
-// position of the decision bit of the thread's new-state register r = 2k+b (butterfly k, input bit b), frame half h
+// position of the decision bit of the thread's register r (0..15), frame half h, inside the step's decision dword
 __host__ __device__ constexpr u32 lds2_dec_bit(u32 r, u32 h) { return (r & 7u) + 8u * h + 16u * ((r >> 3) & 1u); }
+
+// state held by register r of thread j after stage c of a block (c = -1: as loaded), sbits = K-1
+__host__ __device__ constexpr u32 lds2_state_of(int c, u32 r, u32 j, int sbits) {
+    const int nlow = c + 1, jb = sbits - 4;
+    return ((r & ((1u << (4 - nlow)) - 1u)) << (jb + nlow)) | (j << nlow) | (r >> (4 - nlow));
+}
+// inverse: the thread and register that hold the decision of NEXT-state s at trellis step t (stage t % 4)
+__host__ __device__ inline void lds2_locate(u32 s, u32 t, int sbits, u32& j, u32& r) {
+    const int nlow = (int)(t & 3u) + 1, jb = sbits - 4;
+    j = (s >> nlow) & ((1u << jb) - 1u);
+    r = ((s & ((1u << nlow) - 1u)) << (4 - nlow)) | (s >> (jb + nlow));
+}
 
 template <int K>
 struct Lds2Geom {
-    static constexpr int N = 1 << (K - 1), H = N / 2, BPT = 8, T = H / BPT, NW = T / 64;
-    static constexpr int RING = 2 * NW;                // branch-metric tables in flight
-    static constexpr size_t smem_bytes = (size_t)2 * N * 4 + (size_t)RING * 64 * 8 + (size_t)NW * 4 + 16;
+    static constexpr int SBITS = K - 1, N = 1 << SBITS, H = N / 2, T = N / 16, NW = T / 64;
+    static constexpr int BLK = 4;                          // trellis steps per barrier
+    static constexpr int CPW = (BLK + NW - 1) / NW;        // tables a wavefront builds per block
+    static constexpr size_t smem_bytes = (size_t)2 * N * 4 + (size_t)2 * BLK * 64 * 8 + (size_t)NW * 4 + 16;
     static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..15");
 };
 
 template <int K, int SHIFT>
 __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateArgs a) {
     using GM = Lds2Geom<K>;
-    constexpr int N = GM::N, H = GM::H, BPT = GM::BPT, T = GM::T, NW = GM::NW, RING = GM::RING;
+    constexpr int N = GM::N, T = GM::T, NW = GM::NW, BLK = GM::BLK, CPW = GM::CPW, SBITS = GM::SBITS;
     constexpr u32 BIAS2 = 0x80008000u;
     extern __shared__ __attribute__((aligned(16))) u32 lds2_smem[];
-    u32* met_old = lds2_smem;
-    u32* met_new = lds2_smem + N;
-    uint2* etab = (uint2*)(lds2_smem + 2 * N);             // [RING][64] {E, max_error - E}
-    u32* wmin = (u32*)(etab + RING * 64);             // [NW]
+    u32* const met = lds2_smem;                                // [2][N]
+    uint2* const etab = (uint2*)(lds2_smem + 2 * N);           // [2][BLK][64] {E, max_error - E}
+    u32* const wmin = (u32*)(etab + 2 * BLK * 64);             // [NW]
+    u32* const flag = wmin + NW;                               // [2] mid-block renormalisation seen by thread 0; [2] scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 pair = blockIdx.x;
@@ -88,17 +117,23 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     const bool validB = fA + 1 < a.frames;
     const u32 fB = validB ? fA + 1 : fA;
     const int R = a.R;
-    constexpr int SBY = SHIFT ? 1 : 2;
 
     const u32 HIGH2 = (u32)(uint16_t)a.cfg.high * 0x10001u, LOW2 = (u32)(uint16_t)a.cfg.low * 0x10001u;
     const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u;
     const u32 THRM1B2 = ((u32)(uint16_t)(a.cfg.threshold - 1) * 0x10001u) ^ BIAS2;   // metric >= thr  <=>  biased > this
     const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
 
-    // ---- loop-invariant per-thread constants: branch pattern of each of my 8 butterflies (table row offset) ----
-    u32 prow[BPT];
-#pragma unroll
-    for (int k = 0; k < BPT; ++k) prow[k] = (u32)a.pattern[tid + T * k] & 63u;
+    // ---- loop-invariant per-thread constants: table byte offset of the branch pattern of each of my 4 x 8 butterflies ----
+    u32 prow[BLK][8];
+    l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int C = decltype(cc)::value, PB = 3 - C;
+        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
+            constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
+            const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
+            prow[C][h] = ((u32)a.pattern[lower] & 63u) * 8u;
+        });
+    });
 
     // ---- reset (viterbi_decoder_core.h:202-211) ----
     {
@@ -107,8 +142,9 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         for (int s = tid; s < N; s += T) {
             const u32 lo = ((u32)s == sA) ? a.cfg.init_start : a.cfg.init_non_start;
             const u32 hi = ((u32)s == sB) ? a.cfg.init_start : a.cfg.init_non_start;
-            met_old[s] = (lo | (hi << 16)) ^ BIAS2;
+            met[s] = (lo | (hi << 16)) ^ BIAS2;
         }
+        if (tid < 4) flag[tid] = 0;
     }
 
     // ---- branch-metric table builder: lane p makes entry p of the table of one step ----
@@ -131,7 +167,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             }
         }
     };
-    auto build_table = [&](u32 step, const u32 (&y)[8]) __attribute__((always_inline)) {
+    auto build_table = [&](uint2* tab, const u32 (&y)[8]) __attribute__((always_inline)) {
         // E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107)
         u32 e = 0;
 #pragma unroll
@@ -142,84 +178,174 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
                 e = l2_add(e, l2_max_s(d, l2_sub(0u, d)));   // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71)
             }
         }
-        etab[(step % RING) * 64 + lane] = make_uint2(e, l2_sub(MAXE2, e));
+        tab[lane] = make_uint2(e, l2_sub(MAXE2, e));
     };
-    u32 ysym[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // prologue: wave w builds the tables of steps w, and prefetches the symbols of step w + NW (its first in-loop build)
-    if ((u32)wave < a.n_steps) {
-        load_syms((u32)wave, ysym);
-        build_table((u32)wave, ysym);
-    }
-    if ((u32)wave + NW < a.n_steps) load_syms((u32)wave + NW, ysym);
+    // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
+    u32 ysym[CPW][8];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ysym[i][k] = 0;
+    auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int c = wave + NW * i;
+            if (c < BLK && t0 + (u32)c < a.n_steps) load_syms(t0 + (u32)c, ysym[i]);
+        }
+    };
+    auto tables_build = [&](u32 t0, int buf) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int c = wave + NW * i;
+            if (c < BLK && t0 + (u32)c < a.n_steps) build_table(etab + (buf * BLK + c) * 64, ysym[i]);
+        }
+    };
+    tables_load(0);
+    tables_build(0, 0);
+    tables_load(BLK);
     __syncthreads();
 
     uint64_t rsA = 0, rsB = 0;
-    u32* ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
+    u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
-    for (u32 t = 0; t < a.n_steps; ++t) {
-        // ---- my turn to build: table of step t + NW (symbols were loaded NW steps ago), then prefetch t + 2 NW ----
-        if ((int)(t % NW) == wave) {
-            if (t + NW < a.n_steps) build_table(t + NW, ysym);
-            if (t + 2 * NW < a.n_steps) load_syms(t + 2 * NW, ysym);
-        }
-        const uint2* tab = etab + (t % RING) * 64;
-        // ---- add-compare-select for my 8 butterflies  (scalar.h:113-134) ----
-        u32 nm[2 * BPT], D[2 * BPT];
-#pragma unroll
-        for (int k = 0; k < BPT; ++k) {
-            const int j = tid + T * k;
-            const u32 ma = met_old[j], mb = met_old[j + H];
-            const uint2 ee = tab[prow[k]];
-            const u32 x0 = l2_add(ma, ee.x), y0 = l2_add(mb, ee.y);   // -> next state 2j
-            const u32 x1 = l2_add(ma, ee.y), y1 = l2_add(mb, ee.x);   // -> next state 2j+1
-            nm[2 * k] = l2_min_s(x0, y0);
-            nm[2 * k + 1] = l2_min_s(x1, y1);
-            D[2 * k] = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
-            D[2 * k + 1] = l2_sub_sat_s(y1, x1);
-            *(uint2*)(met_new + 2 * j) = make_uint2(nm[2 * k], nm[2 * k + 1]);
-        }
-        // ---- gather the 2 x 16 sign bits: bytes 1 and 3 of the register pair (r, r+8) ----
-        {
-            constexpr u32 SIGNS = 0x80808080u, HI_BYTES = 0x07050301u;
-            u32 lo4 = 0, hi4 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lo4 = (__builtin_amdgcn_perm(D[k + 8], D[k], HI_BYTES) & SIGNS) | (lo4 >> 1);
-                hi4 = (__builtin_amdgcn_perm(D[k + 12], D[k + 4], HI_BYTES) & SIGNS) | (hi4 >> 1);
+    u32 m[16];
+    // one trellis step on the registers: stage C of a block, table `tab`, decisions of step t -> ws  (scalar.h:113-134)
+    auto stage = [&](auto cc, const uint2* tab, u32 t) __attribute__((always_inline)) {
+        constexpr int C = decltype(cc)::value, PB = 3 - C;
+        u32 D[16];
+        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
+            constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
+            const uint2 ee = *(const uint2*)((const char*)tab + prow[C][h]);
+            const u32 ma = m[r0], mb = m[r1];
+            const u32 x0 = l2_add(ma, ee.x), y0 = l2_add(mb, ee.y);   // -> next state 2a
+            const u32 x1 = l2_add(ma, ee.y), y1 = l2_add(mb, ee.x);   // -> next state 2a+1
+            m[r0] = l2_min_s(x0, y0);
+            m[r1] = l2_min_s(x1, y1);
+            D[r0] = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
+            D[r1] = l2_sub_sat_s(y1, x1);
+        });
+        // gather the 2 x 16 sign bits: v_perm selectors 8..11 replicate a half's sign over a byte (clean 0x00 / 0xFF), pair
+        // (r, r+8) lands in bit r%8 of bytes {A r, B r, A r+8, B r+8}
+        constexpr u32 SIGN_BYTES = 0x0b0a0908u;
+        u32 lo4 = 0, hi4 = 0;
+        l2_static_for<4>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const u32 pl = __builtin_amdgcn_perm(D[k + 8], D[k], SIGN_BYTES);
+            const u32 ph = __builtin_amdgcn_perm(D[k + 12], D[k + 4], SIGN_BYTES);
+            if constexpr (k == 0) {
+                lo4 = pl & 0x01010101u;
+                hi4 = ph & 0x10101010u;
+            } else {
+                lo4 = l2_and_or(pl, 0x01010101u << k, lo4);
+                hi4 = l2_and_or(ph, 0x10101010u << k, hi4);
             }
-            ws_pair[(size_t)t * T + tid] = (lo4 >> 4) | hi4;
-        }
+        });
+        ws_pair[(size_t)t * T + tid] = lo4 | hi4;
+    };
+    auto load_metrics = [&](const u32* src) __attribute__((always_inline)) {
+        l2_static_for<16>([&](auto rc) __attribute__((always_inline)) { constexpr int r = decltype(rc)::value; m[r] = src[tid + r * T]; });
+    };
+    auto store_metrics = [&](u32* dst) __attribute__((always_inline)) {      // after stage 3: register r holds state 16 j + r
+        l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            *(uint4*)(dst + 16 * tid + 4 * q) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+        });
+    };
+    // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
+    auto renormalise = [&](u32 need) __attribute__((always_inline)) {
+        const u32 msk = ((need & 0x8000u) ? 0x0000FFFFu : 0u) | ((need & 0x80000000u) ? 0xFFFF0000u : 0u);
+        u32 mn = m[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mn = l2_min_s(mn, m[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));
+        if (lane == 0) wmin[wave] = mn;
         __syncthreads();
-        // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153): block-uniform ----
-        const u32 need = (l2_sub_sat_s(THRM1B2, met_new[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
-        if (need != 0) {
-            const u32 msk = ((need & 0x8000u) ? 0x0000FFFFu : 0u) | ((need & 0x80000000u) ? 0xFFFF0000u : 0u);
-            u32 mn = nm[0];
+        for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wmin[w]);
+        const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
 #pragma unroll
-            for (int i = 1; i < 2 * BPT; ++i) mn = l2_min_s(mn, nm[i]);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));
-            if (lane == 0) wmin[wave] = mn;
-            __syncthreads();
-            for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wmin[w]);
-            const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) {
-                const int j = tid + T * k;
-                *(uint2*)(met_new + 2 * j) = make_uint2(l2_sub(nm[2 * k], sub), l2_sub(nm[2 * k + 1], sub));
+        for (int i = 0; i < 16; ++i) m[i] = l2_sub(m[i], sub);
+        rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
+        rsB += (uint64_t)((sub >> 16) >> SHIFT);
+        __syncthreads();                      // wmin may be rewritten by the next reduction
+    };
+    // the careful version of a block: `nst` stages (1..4) with the threshold test and the reduction after EVERY stage; used
+    // when thread 0 saw state 0 cross the threshold inside a block, and for the last partial block of a frame
+    auto slow_block = [&](u32 t0, int buf, int nst) __attribute__((always_inline)) {
+        const u32* src = met + buf * N;
+        u32* dst = met + (buf ^ 1) * N;
+        load_metrics(src);
+        l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int C = decltype(cc)::value;
+            if (C < nst) {
+                stage(cc, etab + (buf * BLK + C) * 64, t0 + C);
+                // state 0 is register 0 of thread 0 after every stage
+                if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
+                __syncthreads();
+                const u32 need = flag[2];
+                __syncthreads();
+                if (need != 0) renormalise(need);
+                if (C == nst - 1) {
+                    if (C == BLK - 1) {
+                        store_metrics(dst);
+                    } else {
+                        l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
+                            constexpr u32 r = decltype(rc)::value;
+                            dst[lds2_state_of(C, r, (u32)tid, SBITS)] = m[r];
+                        });
+                    }
+                }
             }
-            rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
-            rsB += (uint64_t)((sub >> 16) >> SHIFT);
+        });
+        __syncthreads();
+    };
+    // the fast version: four stages back to back, one barrier.  Returns true when thread 0 saw state 0 reach the threshold
+    // after stage 0, 1 or 2: the block's results are then void and the caller re-runs it with slow_block()
+    auto fast_block = [&](auto bufc, u32 t0) __attribute__((always_inline)) -> bool {
+        constexpr int buf = decltype(bufc)::value;
+        const u32* src = met + buf * N;
+        u32* dst = met + (buf ^ 1) * N;
+        // tables of the NEXT block from the symbols fetched during the previous one, then fetch the block after
+        tables_build(t0 + BLK, buf ^ 1);
+        tables_load(t0 + 2 * BLK);
+        load_metrics(src);
+        u32 mid = 0;
+        l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int C = decltype(cc)::value;
+            stage(cc, etab + (buf * BLK + C) * 64, t0 + C);
+            if (C < BLK - 1 && wave == 0) mid |= (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
+        });
+        store_metrics(dst);
+        if (tid == 0) flag[buf] = mid;
+        __syncthreads();
+        if (flag[buf] != 0) return true;
+        // renormalise when new_metric[0] >= threshold after the block's last step: block-uniform
+        const u32 need = (l2_sub_sat_s(THRM1B2, dst[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
+        if (need != 0) {
+            renormalise(need);
+            store_metrics(dst);
             __syncthreads();
         }
-        u32* tmp = met_old;   // m_metrics.swap()  (scalar.h:51)
-        met_old = met_new;
-        met_new = tmp;
+        return false;
+    };
+
+    u32 t0 = 0;
+    int cur = 0;                              // metric / table buffer that holds the state of step t0
+    while (t0 < a.n_steps) {
+        const u32 left = a.n_steps - t0;
+        const int nst = left < (u32)BLK ? (int)left : BLK;
+        bool slow = nst < BLK;                // last, partial block: its tables were built by the block (or prologue) before
+        if (!slow) slow = cur == 0 ? fast_block(std::integral_constant<int, 0>{}, t0) : fast_block(std::integral_constant<int, 1>{}, t0);
+        if (slow) slow_block(t0, cur, nst);
+        t0 += (u32)nst;
+        cur ^= 1;
     }
 
+    const u32* fin = met + cur * N;
     if (a.metrics_out) {
         for (int s = tid; s < N; s += T) {
-            const u32 v = met_old[s] ^ BIAS2;
+            const u32 v = fin[s] ^ BIAS2;
             if (SHIFT) {
                 ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
                 if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(v >> 24);
@@ -245,13 +371,12 @@ struct Lds2ChainbackArgs {
     int32_t K;
 };
 
-// one lane per frame; the decision dword of (step t, state s): ws[pair][t][(s>>1) % T], bit of register 2*((s>>1)/T) + (s&1)
+// one lane per frame; the decision dword of (step t, next-state s): ws[pair][t][j], bit of register r -- lds2_locate()
 __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.frames) return;
     const int TSB = a.K - 1;
-    const u32 T = (1u << (TSB - 1)) / 8u;
-    const u32 tshift = (u32)(TSB - 1 - 3);           // log2(T)
+    const u32 T = (1u << TSB) / 16u;
     const int ignore = TSB < 8 ? TSB : 8;           // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     const int shift_state = 8 - ignore, shift_tail = TSB - ignore, total_bits = TSB + shift_state;
     const u32* ws = a.ws + (f >> 1) * a.ws_pair_stride;
@@ -260,9 +385,10 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     u32 reg = (a.end_state ? (a.end_state[f] & ((1u << TSB) - 1u)) : 0u) << shift_state;
     for (size_t j = a.L; j-- > 0;) {
         const u32 state = reg >> shift_state;
-        const u32 jj = state >> 1;
-        const u32 r = 2u * (jj >> tshift) + (state & 1u);
-        const u32 w = ws[(j + (size_t)TSB) * T + (jj & (T - 1u))];
+        const u32 t = (u32)(j + (size_t)TSB);
+        u32 tj, r;
+        lds2_locate(state, t, TSB, tj, r);
+        const u32 w = ws[(size_t)t * T + tj];
         const u32 bit = (w >> lds2_dec_bit(r, half)) & 1u;
         reg = (reg >> 1) | (bit << (total_bits - 1));
         if ((j & 7) == 0) out[j >> 3] = (uint8_t)((reg >> shift_tail) & 0xFFu);
@@ -280,8 +406,7 @@ struct Lds2ExportArgs {
 __global__ void lds2_export_kernel(Lds2ExportArgs a) {
     const int TSB = a.K - 1;
     const u32 W = 1u << (TSB - 6);
-    const u32 T = (1u << (TSB - 1)) / 8u;
-    const u32 tshift = (u32)(TSB - 1 - 3);
+    const u32 T = (1u << TSB) / 16u;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (frame, step, word)
     const size_t total = (size_t)a.frames * a.n_steps * W;
     if (idx >= total) return;
@@ -292,17 +417,16 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
     const u32 half = f & 1u;
     uint64_t word = 0;
     for (u32 b = 0; b < 64; ++b) {
-        const u32 s = w * 64 + b;
-        const u32 jj = s >> 1;
-        const u32 r = 2u * (jj >> tshift) + (s & 1u);
-        word |= (uint64_t)((ws[jj & (T - 1u)] >> lds2_dec_bit(r, half)) & 1u) << b;
+        u32 tj, r;
+        lds2_locate(w * 64 + b, t, TSB, tj, r);
+        word |= (uint64_t)((ws[tj] >> lds2_dec_bit(r, half)) & 1u) << b;
     }
     a.out[idx] = word;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 inline bool lds2_supported(int K, int R) { return K >= 11 && K <= 15 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
-inline size_t lds2_threads(int K) { return ((size_t)1 << (K - 2)) / 8; }
+inline size_t lds2_threads(int K) { return ((size_t)1 << (K - 1)) / 16; }
 inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
     return ((frames + 1) / 2) * (L + (size_t)K - 1) * lds2_threads(K) * 4;
 }
