@@ -76,8 +76,14 @@ struct Lds2UpdateArgs {
     DevConfig cfg;
 };
 
-// position of the decision bit of the thread's register r (0..15), frame half h, inside the step's decision dword
-__host__ __device__ constexpr u32 lds2_dec_bit(u32 r, u32 h) { return (r & 7u) + 8u * h + 16u * ((r >> 3) & 1u); }
+// position of the decision bit of the thread's register r (0..15), frame half h, inside the decision dword of a step that
+// ran as stage c of its block: the two registers of butterfly b (r without its bit 3-c) are gathered together as bytes
+// {A r0, B r0, A r1, B r1}, bit b of each
+__host__ __device__ constexpr u32 lds2_dec_bit(u32 r, u32 h, u32 c) {
+    const u32 pb = 3u - c;
+    const u32 b = ((r >> (pb + 1u)) << pb) | (r & ((1u << pb) - 1u));
+    return b + 8u * h + 16u * ((r >> pb) & 1u);
+}
 
 // state held by register r of thread j after stage c of a block (c = -1: as loaded), sbits = K-1
 __host__ __device__ constexpr u32 lds2_state_of(int c, u32 r, u32 j, int sbits) {
@@ -91,12 +97,22 @@ __host__ __device__ inline void lds2_locate(u32 s, u32 t, int sbits, u32& j, u32
     r = ((s & ((1u << nlow) - 1u)) << (4 - nlow)) | (s >> (jb + nlow));
 }
 
+// LDS index of natural state s inside a metric buffer of n states.  The natural order makes the four ds_write_b128 of a
+// thread's 16 new states (64-byte lane stride) 4-way bank conflicts; this order keeps BOTH access patterns of a block
+// conflict free: write view s = 16 J + 4 q + i  ->  piece q of thread J is 16 contiguous bytes at q*n/4 + 4*(J ^ 2q)
+// (8 consecutive J cover all 32 banks), read view s = r*T + j -> for 32 consecutive j the low bits (i, q, J0) still map to
+// 32 different banks because q is folded into bits 1-2 of J.  sw(0) = 0.
+__host__ __device__ constexpr u32 lds2_sw(u32 s, u32 n) {
+    const u32 q = (s >> 2) & 3u;
+    return q * (n / 4u) + (((s >> 4) ^ (q << 1)) << 2) + (s & 3u);
+}
+
 template <int K>
 struct Lds2Geom {
     static constexpr int SBITS = K - 1, N = 1 << SBITS, H = N / 2, T = N / 16, NW = T / 64;
     static constexpr int BLK = 4;                          // trellis steps per barrier
     static constexpr int CPW = (BLK + NW - 1) / NW;        // tables a wavefront builds per block
-    static constexpr size_t smem_bytes = (size_t)2 * N * 4 + (size_t)2 * BLK * 64 * 8 + (size_t)NW * 4 + 16;
+    static constexpr size_t smem_bytes = (size_t)2 * N * 4 + (size_t)2 * BLK * 64 * 8 + 32 * 4;
     static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..15");
 };
 
@@ -106,10 +122,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     constexpr int N = GM::N, T = GM::T, NW = GM::NW, BLK = GM::BLK, CPW = GM::CPW, SBITS = GM::SBITS;
     constexpr u32 BIAS2 = 0x80008000u;
     extern __shared__ __attribute__((aligned(16))) u32 lds2_smem[];
-    u32* const met = lds2_smem;                                // [2][N]
-    uint2* const etab = (uint2*)(lds2_smem + 2 * N);           // [2][BLK][64] {E, max_error - E}
-    u32* const wmin = (u32*)(etab + 2 * BLK * 64);             // [NW]
-    u32* const flag = wmin + NW;                               // [2] mid-block renormalisation seen by thread 0; [2] scratch
+    // tables first: their byte offsets (< 4 KiB) fit instruction offsets and 16-bit halves of a register
+    uint2* const etab = (uint2*)lds2_smem;                     // [2][BLK][64] {E, max_error - E}
+    u32* const wmin = (u32*)(etab + 2 * BLK * 64);             // [16]
+    u32* const flag = wmin + 16;                               // [2] mid-block renormalisation seen by thread 0; [2] scratch
+    u32* const met = flag + 16;                                // [2][N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 pair = blockIdx.x;
@@ -124,14 +141,23 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
 
     // ---- loop-invariant per-thread constants: table byte offset of the branch pattern of each of my 4 x 8 butterflies ----
-    u32 prow[BLK][8];
+    // (two 16-bit LDS byte offsets per register: 16 registers instead of 32 keep the kernel inside the 128 VGPRs that
+    // 1024-thread workgroups get; unpacking costs one 2.5-cycle and/shift per table read)
+    u32 prow2[BLK][4];
     l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
-        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
-            constexpr int h = decltype(hc)::value;
-            constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
-            const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
-            prow[C][h] = ((u32)a.pattern[lower] & 63u) * 8u;
+        l2_static_for<4>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h2 = decltype(hc)::value;
+            u32 pk = 0;
+            l2_static_for<2>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int h = 2 * h2 + decltype(ec)::value;
+                constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
+                const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
+                // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + BLK*512, an instruction offset)
+                const u32 off = (u32)(C * 512) + ((u32)a.pattern[lower] & 63u) * 8u;
+                pk |= off << (16 * decltype(ec)::value);
+            });
+            prow2[C][h2] = pk;
         });
     });
 
@@ -142,7 +168,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         for (int s = tid; s < N; s += T) {
             const u32 lo = ((u32)s == sA) ? a.cfg.init_start : a.cfg.init_non_start;
             const u32 hi = ((u32)s == sB) ? a.cfg.init_start : a.cfg.init_non_start;
-            met[s] = (lo | (hi << 16)) ^ BIAS2;
+            met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
         }
         if (tid < 4) flag[tid] = 0;
     }
@@ -150,10 +176,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     // ---- branch-metric table builder: lane p makes entry p of the table of one step ----
     const uint8_t* symA = a.symbols + (size_t)fA * a.sym_frame_stride_bytes;
     const uint8_t* symB = a.symbols + (size_t)fB * a.sym_frame_stride_bytes;
-    auto load_syms = [&](u32 step, u32 (&y)[8]) __attribute__((always_inline)) {
+    auto load_syms = [&](u32 step, u32 (&y)[6]) __attribute__((always_inline)) {
         // packed (frame A | frame B << 16) symbols of `step` in the device's 16-bit domain
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 6; ++i) {
             if (i < R) {
                 u32 ya, yb;
                 if (SHIFT) {
@@ -167,11 +193,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             }
         }
     };
-    auto build_table = [&](uint2* tab, const u32 (&y)[8]) __attribute__((always_inline)) {
+    auto build_table = [&](uint2* tab, const u32 (&y)[6]) __attribute__((always_inline)) {
         // E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107)
         u32 e = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 6; ++i) {
             if (i < R) {
                 const u32 bt = ((lane >> i) & 1) ? HIGH2 : LOW2;
                 const u32 d = l2_sub(bt, y[i]);
@@ -181,11 +207,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         tab[lane] = make_uint2(e, l2_sub(MAXE2, e));
     };
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
-    u32 ysym[CPW][8];
+    u32 ysym[CPW][6];                        // lds2_supported(): R <= 6
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ysym[i][k] = 0;
+        for (int k = 0; k < 6; ++k) ysym[i][k] = 0;
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
@@ -210,46 +236,46 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
 
     u32 m[16];
     // one trellis step on the registers: stage C of a block, table `tab`, decisions of step t -> ws  (scalar.h:113-134)
-    auto stage = [&](auto cc, const uint2* tab, u32 t) __attribute__((always_inline)) {
+    auto stage = [&](auto cc, u32 tabset_bytes, u32* wsp) __attribute__((always_inline)) {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
-        u32 D[16];
+        // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
+        // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
+        constexpr u32 SIGN_BYTES = 0x0b0a0908u;
+        u32 lo4 = 0, hi4 = 0;
         l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value;
             constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
-            const uint2 ee = *(const uint2*)((const char*)tab + prow[C][h]);
+            const u32 off = (h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu);
+            const uint2 ee = *(const uint2*)((const char*)lds2_smem + off + tabset_bytes);
             const u32 ma = m[r0], mb = m[r1];
             const u32 x0 = l2_add(ma, ee.x), y0 = l2_add(mb, ee.y);   // -> next state 2a
             const u32 x1 = l2_add(ma, ee.y), y1 = l2_add(mb, ee.x);   // -> next state 2a+1
             m[r0] = l2_min_s(x0, y0);
             m[r1] = l2_min_s(x1, y1);
-            D[r0] = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
-            D[r1] = l2_sub_sat_s(y1, x1);
+            const u32 d0 = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
+            const u32 d1 = l2_sub_sat_s(y1, x1);
+            const u32 sg = __builtin_amdgcn_perm(d1, d0, SIGN_BYTES);
+            if constexpr (h == 0) lo4 = sg & 0x01010101u;
+            else if constexpr (h == 1) hi4 = sg & 0x02020202u;
+            else if constexpr (h % 2 == 0) lo4 = l2_and_or(sg, 0x01010101u << h, lo4);
+            else hi4 = l2_and_or(sg, 0x01010101u << h, hi4);
         });
-        // gather the 2 x 16 sign bits: v_perm selectors 8..11 replicate a half's sign over a byte (clean 0x00 / 0xFF), pair
-        // (r, r+8) lands in bit r%8 of bytes {A r, B r, A r+8, B r+8}
-        constexpr u32 SIGN_BYTES = 0x0b0a0908u;
-        u32 lo4 = 0, hi4 = 0;
-        l2_static_for<4>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            const u32 pl = __builtin_amdgcn_perm(D[k + 8], D[k], SIGN_BYTES);
-            const u32 ph = __builtin_amdgcn_perm(D[k + 12], D[k + 4], SIGN_BYTES);
-            if constexpr (k == 0) {
-                lo4 = pl & 0x01010101u;
-                hi4 = ph & 0x10101010u;
-            } else {
-                lo4 = l2_and_or(pl, 0x01010101u << k, lo4);
-                hi4 = l2_and_or(ph, 0x10101010u << k, hi4);
-            }
-        });
-        ws_pair[(size_t)t * T + tid] = lo4 | hi4;
+        wsp[C * T + tid] = lo4 | hi4;
     };
+    // swizzled metric buffers (lds2_sw): read view, register r = state r*T + j; write view, piece q = states 16 j + 4 q ...
+    constexpr bool SEP = (T / 16) % 8 == 0;     // r*T/16 does not reach the three bits the swizzle touches: base + r*T/4
+    const u32 rd_base = lds2_sw((u32)tid, (u32)N);
     auto load_metrics = [&](const u32* src) __attribute__((always_inline)) {
-        l2_static_for<16>([&](auto rc) __attribute__((always_inline)) { constexpr int r = decltype(rc)::value; m[r] = src[tid + r * T]; });
+        l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (SEP) m[r] = src[rd_base + r * (T / 4)];
+            else m[r] = src[lds2_sw((u32)(r * T) + (u32)tid, (u32)N)];
+        });
     };
     auto store_metrics = [&](u32* dst) __attribute__((always_inline)) {      // after stage 3: register r holds state 16 j + r
         l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
-            *(uint4*)(dst + 16 * tid + 4 * q) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+            *(uint4*)(dst + q * (N / 4) + (((u32)tid ^ (u32)(q << 1)) << 2)) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
         });
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
@@ -279,7 +305,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
             if (C < nst) {
-                stage(cc, etab + (buf * BLK + C) * 64, t0 + C);
+                stage(cc, (u32)(buf * BLK * 512), ws_pair + (size_t)t0 * T);
                 // state 0 is register 0 of thread 0 after every stage
                 if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
                 __syncthreads();
@@ -292,7 +318,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
                     } else {
                         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
                             constexpr u32 r = decltype(rc)::value;
-                            dst[lds2_state_of(C, r, (u32)tid, SBITS)] = m[r];
+                            dst[lds2_sw(lds2_state_of(C, r, (u32)tid, SBITS), (u32)N)] = m[r];
                         });
                     }
                 }
@@ -310,10 +336,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         tables_build(t0 + BLK, buf ^ 1);
         tables_load(t0 + 2 * BLK);
         load_metrics(src);
+        u32* const wsp = ws_pair + (size_t)t0 * T;   // uniform: the four decision rows of this block
         u32 mid = 0;
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
-            stage(cc, etab + (buf * BLK + C) * 64, t0 + C);
+            stage(cc, (u32)(buf * BLK * 512), wsp);
             if (C < BLK - 1 && wave == 0) mid |= (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
         });
         store_metrics(dst);
@@ -345,7 +372,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     const u32* fin = met + cur * N;
     if (a.metrics_out) {
         for (int s = tid; s < N; s += T) {
-            const u32 v = fin[s] ^ BIAS2;
+            const u32 v = fin[lds2_sw((u32)s, (u32)N)] ^ BIAS2;
             if (SHIFT) {
                 ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
                 if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(v >> 24);
@@ -389,7 +416,7 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
         u32 tj, r;
         lds2_locate(state, t, TSB, tj, r);
         const u32 w = ws[(size_t)t * T + tj];
-        const u32 bit = (w >> lds2_dec_bit(r, half)) & 1u;
+        const u32 bit = (w >> lds2_dec_bit(r, half, t & 3u)) & 1u;
         reg = (reg >> 1) | (bit << (total_bits - 1));
         if ((j & 7) == 0) out[j >> 3] = (uint8_t)((reg >> shift_tail) & 0xFFu);
     }
@@ -419,7 +446,7 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
     for (u32 b = 0; b < 64; ++b) {
         u32 tj, r;
         lds2_locate(w * 64 + b, t, TSB, tj, r);
-        word |= (uint64_t)((ws[tj] >> lds2_dec_bit(r, half)) & 1u) << b;
+        word |= (uint64_t)((ws[tj] >> lds2_dec_bit(r, half, t & 3u)) & 1u) << b;
     }
     a.out[idx] = word;
 }
