@@ -166,6 +166,7 @@ struct RegUpdateArgs {
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
 typedef int v2i32_t __attribute__((ext_vector_type(2)));
+typedef int v3i32_t __attribute__((ext_vector_type(3)));
 // 16 bytes of a frame's symbol stream through a bounds-checked buffer descriptor: bytes at or beyond the end of the
 // caller's buffer read as zero in hardware (no branches, no over-read).  `voff` is dword aligned; when a frame does not
 // start on a dword (odd strides: R = 3 with 8-bit symbols) `fix` is set wave-wide and the 16 bytes are funnel-shifted
@@ -194,13 +195,19 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // ONCE (with the unswapped high / low) and parks them in an LDS ring; every step each lane then fetches
     // E[p ^ pat_lane(phase, q)] with one ds_read_b64 per pattern through per-lane addresses.  22 VALU per lane and step
     // become 6 (+ 4 LDS reads that issue beside the other wave's VALU).
-    constexpr bool LDSBM = SP::LANE_BITS == 2 && R == 2;
+    constexpr bool LDSBM = SP::LANE_BITS == 2;
     constexpr int GROUP = 4;
     // unrolled block: whole phases, whole decision rows, and whole 16-byte symbol chunks / whole 4-step groups
-    constexpr int U = LDSBM ? clcm(clcm(SB, GROUP), SPS) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
+    constexpr int U0 = clcm(clcm(SB, GROUP), SPS);
+    // LDS ring, in steps: the slot of step t is t % RING, a compile-time constant because RING divides the block length; 16 KiB
+    // per wave at most, so that eight waves still fit a CU (R = 4 with 6 state bits: 8 steps, block of 24)
+    constexpr int RING = !LDSBM ? 1 : (U0 * NP * 128 <= 16384 ? U0 : 8);
+    constexpr int U = LDSBM ? clcm(U0, RING) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
     constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
-    constexpr int NG = U / GROUP;                 // groups per block == depth of the symbol register ring
-    constexpr int RING = U;                       // LDS ring, in steps: slot of step t = t % U is a compile-time constant
+    constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 3 == 0 ? 3 : 2);   // depth of the symbol register ring, in groups
+    constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
+    static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
+    constexpr bool RDTAB = SB * NP <= 32;         // read indices per (phase, pattern) in registers; else per phase + one v_xor per read
     constexpr int ROW = NP * 16;                  // uint2 {E, EB} entries per step: [pattern][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
@@ -257,20 +264,24 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     }
     // LDSBM: ring index (uint2 units) this lane READS pattern p from in phase ph: entry (p ^ pat_lane(ph, q)) of pair g;
     // and the one it WRITES its own step of a group to (step 4J+q: row q of the group, pattern 0, pair g)
-    u32 rd_idx[LDSBM ? SB : 1][NP];
+    u32 rd_idx[LDSBM && RDTAB ? SB : 1][NP], rd_x[LDSBM && !RDTAB ? SB : 1];
     const u32 wr_idx = q * ROW + g;
     if constexpr (LDSBM) {
         static_for<SB>([&](auto pc) __attribute__((always_inline)) {
             constexpr int ph = decltype(pc)::value;
             const u32 x = q == 0 ? SP::pat_lane(ph, 0) : q == 1 ? SP::pat_lane(ph, 1) : q == 2 ? SP::pat_lane(ph, 2) : SP::pat_lane(ph, 3);
-            static_for<NP>([&](auto ppc) __attribute__((always_inline)) {
-                constexpr u32 p = decltype(ppc)::value;
-                rd_idx[ph][p] = ((p ^ x) << 4) + g;
-            });
+            if constexpr (RDTAB) {
+                static_for<NP>([&](auto ppc) __attribute__((always_inline)) {
+                    constexpr u32 p = decltype(ppc)::value;
+                    rd_idx[ph][p] = ((p ^ x) << 4) + g;
+                });
+            } else {
+                rd_x[ph] = (x << 4) | g;          // ((p ^ x) << 4) + g == rd_x ^ (p << 4) because g < 16
+            }
         });
     }
-    // LDSBM symbol fetch: the BPS bytes of step 4J+q sit at byte rawX + BPS*q + 4*BPS*J of the tile: an 8-byte load from
-    // the dword below and a per-lane v_alignbyte (4*BPS is a multiple of 4, so the shift is the same for every group)
+    // LDSBM symbol fetch: the BPS bytes of step 4J+q sit at byte rawX + BPS*q + 4*BPS*J of the tile: NDW dwords from the
+    // dword below and per-lane v_alignbyte (4*BPS is a multiple of 4, so the shift is the same for every group)
     const u32 gvA = (rawA + BPS * q) & ~3u, gsA = (rawA + BPS * q) & 3u;
     const u32 gvB = (rawB + BPS * q) & ~3u, gsB = (rawB + BPS * q) & 3u;
 
@@ -295,13 +306,20 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         cB[c] = load_chunk(rsrc, offB + 16 * c, misB, fix);
     });
     // LDSBM: symbols of this lane's step of the next NG groups (register ring, slot = group % NG)
-    u32 gA[NG][2], gB[NG][2];
+    u32 gA[NG][NDW], gB[NG][NDW];
     auto load_group = [&](u32 first_step, auto slotc) __attribute__((always_inline)) {
         constexpr int sl = decltype(slotc)::value;
-        const v2i32_t va = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvA + first_step * BPS), 0, 0);
-        const v2i32_t vb = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvB + first_step * BPS), 0, 0);
-        gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y;
-        gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y;
+        if constexpr (NDW == 2) {
+            const v2i32_t va = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvA + first_step * BPS), 0, 0);
+            const v2i32_t vb = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvB + first_step * BPS), 0, 0);
+            gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y;
+            gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y;
+        } else {
+            const v3i32_t va = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gvA + first_step * BPS), 0, 0);
+            const v3i32_t vb = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gvB + first_step * BPS), 0, 0);
+            gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y; gA[sl][2] = (u32)va.z;
+            gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y; gB[sl][2] = (u32)vb.z;
+        }
     };
 
     uint64_t rsA = 0, rsB = 0;
@@ -348,15 +366,19 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // LDSBM producer: this lane's step of the group whose first step has ring slot `slot0`, from symbol ring slot `sl`
     auto bm_produce = [&](auto slot0c, auto slc) __attribute__((always_inline)) {
         constexpr int slot0 = decltype(slot0c)::value, sl = decltype(slc)::value;
-        const u32 wa = __builtin_amdgcn_alignbyte(gA[sl][1], gA[sl][0], gsA);
-        const u32 wb = __builtin_amdgcn_alignbyte(gB[sl][1], gB[sl][0], gsB);
+        u32 wa[NDW - 1], wb[NDW - 1];             // the step's bytes 4k .. 4k+3 of frame A / B
+        static_for<NDW - 1>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            wa[k] = __builtin_amdgcn_alignbyte(gA[sl][k + 1], gA[sl][k], gsA);
+            wb[k] = __builtin_amdgcn_alignbyte(gB[sl][k + 1], gB[sl][k], gsB);
+        });
         u32 A1[R], A0[R];
         static_for<R>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
-            constexpr int sub = i * SBY;
+            constexpr int k = (i * SBY) / 4, sub = (i * SBY) % 4;
             constexpr u32 sel = SHIFT ? (0x0cu | ((u32)sub << 8) | (0x0cu << 16) | ((u32)(4 + sub) << 24))
                                       : ((u32)sub | ((u32)(sub + 1) << 8) | ((u32)(4 + sub) << 16) | ((u32)(5 + sub) << 24));
-            const u32 Y = __builtin_amdgcn_perm(wb, wa, sel);
+            const u32 Y = __builtin_amdgcn_perm(wb[k], wa[k], sel);
             const u32 d1 = pk_sub(HIGH2, Y), d0 = pk_sub(LOW2, Y);
             A1[i] = pk_max_s(d1, pk_sub(0u, d1));
             A0[i] = pk_max_s(d0, pk_sub(0u, d0));
@@ -382,7 +404,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         constexpr int us = un % U, PHn = us % SB, buf = un & 1;
         static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-            const uint2 v = bm_ring[rd_idx[PHn][p] + us * ROW];
+            u32 idx;
+            if constexpr (RDTAB) idx = rd_idx[PHn][p]; else idx = rd_x[PHn] ^ (u32)(p << 4);
+            const uint2 v = bm_ring[idx + (us % RING) * ROW];
             E[buf][p] = v.x;
             EB[buf][p] = v.y;
         });
