@@ -628,7 +628,7 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
-    constexpr int NBUF = 8;                                    // == SB: a byte completes at a fixed slot of the ring
+    constexpr int NBUF = 16;                                   // multiple of SB = 8: bytes complete at fixed slots of the ring
 
     const int lane = threadIdx.x & 63;
     const u32 g = lane & 15, q = lane >> 4;
@@ -675,18 +675,52 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
         uint4 buf[NBUF];
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(t - b) * 64];
-        for (; t - (NBUF - 1) >= SB; t -= NBUF) {
+        // One pass over the ring = NBUF steps = NBUF/8 output bytes per frame.  Inside the inner loop ONLY loads are
+        // outstanding (see reg_chainback16_body: a pending store makes hipcc drain the ring with vmcnt(0) at every loop top):
+        // the bytes are parked in LDS, [dword][lane][byte] so that neither the byte writes nor the dword reads of the flush
+        // conflict, and flushed as (possibly unaligned) dword stores every KI passes.
+        constexpr int BPP = NBUF / 8;                            // bytes per frame and pass
+        constexpr int KI = 128 / BPP;                            // 128 bytes per frame between flushes
+        __shared__ u32 obufA[32 * 64], obufB[32 * 64];
+        typedef u32 u32_unaligned __attribute__((aligned(1)));
+        while (t - (NBUF - 1) >= SB) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): retire the previous flush (and the ring)
+            const int t_top = t;
+            int it = 0;
+            for (; it < KI && t - (NBUF - 1) >= SB; ++it, t -= NBUF) {
 #pragma unroll
-            for (int b = 0; b < NBUF; ++b) {
-                // step t-b with t % 8 == 7: (t - b + 1) % 8 == (8 - b) % 8
-                constexpr int dummy = 0; (void)dummy;
-                const u32 ph1 = (u32)((NBUF - b) % NBUF);
-                trace(regA, buf[b], 0u, ph1);
-                trace(regB, buf[b], 1u, ph1);
-                if (b == NBUF - 1) emit((u32)(t - b - SB) >> 3);    // j = t-7-8 is a multiple of 8
-                const int nxt = t - b - NBUF;
-                buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
-                __builtin_amdgcn_sched_barrier(0);
+                for (int b = 0; b < NBUF; ++b) {
+                    // step t-b with t % 8 == 7: (t - b + 1) % 8 == (8 - b) % 8
+                    const u32 ph1 = (u32)((8 - (b % 8)) % 8);
+                    trace(regA, buf[b], 0u, ph1);
+                    trace(regB, buf[b], 1u, ph1);
+                    if (b % 8 == 7) {
+                        // j = t-b-8 is a multiple of 8: byte (t-b-8)/8 is complete; slot counts down from the top of the flush
+                        const int slot = 127 - (it * BPP + b / 8);
+                        ((uint8_t*)obufA)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
+                        ((uint8_t*)obufB)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+                    }
+                    asm volatile("" : "+v"(regA), "+v"(regB) : : "memory");   // pin the chase in front of the refill
+                    const int nxt = t - b - NBUF;
+                    buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the passes completed bytes (t_top - 7 - SB)/8 down to (t + 1 - SB)/8 = slots 127 down to 128 - it*BPP
+            if (q == 0) {
+                const int nbytes = it * BPP;
+                const u32 jb_lo = (u32)(t + 1 - SB) >> 3;        // byte index of slot 128 - nbytes
+                (void)t_top;
+                int sl = 128 - nbytes;
+                // leading bytes up to a dword boundary of the slot space, then whole dwords
+                for (; (sl & 3) != 0 && sl < 128; ++sl) {
+                    outA[jb_lo + (u32)(sl - (128 - nbytes))] = ((const uint8_t*)obufA)[(sl >> 2) * 256 + lane * 4 + (sl & 3)];
+                    outB[jb_lo + (u32)(sl - (128 - nbytes))] = ((const uint8_t*)obufB)[(sl >> 2) * 256 + lane * 4 + (sl & 3)];
+                }
+                for (; sl < 128; sl += 4) {
+                    *(u32_unaligned*)(outA + jb_lo + (u32)(sl - (128 - nbytes))) = obufA[(sl >> 2) * 64 + lane];
+                    *(u32_unaligned*)(outB + jb_lo + (u32)(sl - (128 - nbytes))) = obufB[(sl >> 2) * 64 + lane];
+                }
             }
         }
     }
@@ -921,8 +955,13 @@ VIT_DEV void reg_export_body(const RegExportArgs& a) {
 }
 
 // ---- kernels: thin __global__ wrappers (the bodies above are shared with the run-time compiled instantiations) --------
+// two waves per SIMD (<= 256 VGPRs) wherever the tiles of a 65536-frame batch outnumber the SIMDs two to one: left alone
+// hipcc takes 260 registers for K = 9 and halves the occupancy.  K = 9 with R > 2 does not fit (64 metrics + 64 decisions + 64
+// branch metrics) and keeps one wave per SIMD.
+template <class SP>
+constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 : 2; }
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT>(a); }
+__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT>(a); }
 
 // chainback: one kernel name per code, the body is picked by the code's geometry
 template <class SP>

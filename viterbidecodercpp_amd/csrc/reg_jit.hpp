@@ -101,9 +101,9 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
               << "using SP = vit::RegSpec<" << K << ", " << R;
             for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
             f << ", " << lane_bits << ">;\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64) vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64) vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64) vit_jit_chainback(vit::RegChainbackArgs a) { vit::reg_chainback_body<SP>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, 2) vit_jit_chainback(vit::RegChainbackArgs a) { vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
         }
         const char* cc = getenv("VIT_HIP_HIPCC");
