@@ -17,6 +17,9 @@
  *                                                                 examples/helpers/puncture_code_helpers.h:51)
  *   vit_hip_chainback_host    chainback() on host-resident decision rows
  *   vit_hip_export_decisions  ViterbiDecisionBits rows            viterbi_decoder_core.h:49-83 (m_decisions[t][w])
+ *   vit_hip_depuncture_batch  decode_punctured_symbols()          examples/helpers/puncture_code_helpers.h:17-55 (the
+ *                             re-insertion of punctured symbols as the erasure value 0, for a whole batch; the update
+ *                             itself then runs through vit_hip_update_batch instead of one update() per R symbols)
  *
  * Semantics are those of the reference SCALAR strategy (strict '>' decision, wrapping error_t arithmetic,
  * renormalise only when new_metric[0] >= threshold): SURVEY.md section 8(a').  All results are bit-exact.
@@ -118,6 +121,17 @@ int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames,
  * = decision for next-state s at step t. */
 int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t frames, size_t n_steps, size_t L,
                              uint64_t* d_decisions, vit_hip_stream_t stream);
+
+/* Depuncturing front-end for punctured codes (DAB, LTE rate matching ...): builds the [frames][symbols_per_frame] soft_t
+ * stream vit_hip_update_batch consumes from the symbols that were actually transmitted.
+ *   d_punctured     [frames][punctured_per_frame] soft_t, frame-major
+ *   d_source_index  [symbols_per_frame] int32: index into the frame's punctured symbols, or < 0 for a punctured position,
+ *                   which reads as the erasure value 0 (examples/run_punctured_decoder.cpp:165).  The same map serves every
+ *                   frame; for a puncturing mask it is the exclusive prefix sum of the mask where the mask is set.
+ *   d_symbols_out   [frames][symbols_per_frame] soft_t */
+int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t punctured_per_frame,
+                             const int32_t* d_source_index, size_t symbols_per_frame, size_t frames, void* d_symbols_out,
+                             vit_hip_stream_t stream);
 
 /* ---- host-pointer compatibility route (one decoder object, streaming) ------------------------------------------ */
 

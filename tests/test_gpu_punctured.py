@@ -61,3 +61,39 @@ def test_dab_fic_punctured_streaming(oracle, decode_type, ebn0):
     batch = np.ascontiguousarray(np.broadcast_to(depunctured.reshape(1, -1, code.R), (40, depunctured.size // code.R, code.R)))
     out = dec.decode(torch.from_numpy(batch).cuda(), TOTAL_DATA_BITS).cpu().numpy()
     assert all(np.array_equal(out[f], want["bytes"]) for f in range(40))
+
+
+@pytest.mark.parametrize("decode_type", ["SOFT16", "SOFT8", "HARD8"])
+def test_dab_fic_punctured_batch_front_end(oracle, decode_type):
+    """The same scenario at receiver scale: many noisy FIC blocks, depunctured ON THE DEVICE (vit_hip_depuncture_batch) and
+    decoded by the batch route; every frame bit-exact against the oracle fed with the host-depunctured stream."""
+    import torch
+
+    code = COMMON_CODES[4]
+    pc = get_decoding_config(decode_type, code.R)
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    config = ViterbiDecoder_Config.from_decoder_config(pc)
+    F = 37
+    tx, sym = synth.make_frames_numpy(code, pc, F, TOTAL_DATA_BITS, 5.0, seed=7)
+    mask = puncture_mask()
+    flat = sym.reshape(F, -1)
+    transmitted = np.ascontiguousarray(flat[:, mask])
+    depunctured = np.zeros_like(flat)
+    depunctured[:, mask] = transmitted
+
+    dec = BatchDecoder(table, config)
+    d_sym = dec.depuncture(torch.from_numpy(transmitted).cuda(), mask)
+    assert d_sym.shape == (F, TOTAL_DATA_BITS + code.K - 1, code.R)
+    assert np.array_equal(d_sym.cpu().numpy().reshape(F, -1), depunctured)
+    out = dec.decode(d_sym, TOTAL_DATA_BITS).cpu().numpy()
+    for f in range(F):
+        want = oracle.decode(code.K, code.R, code.G, oracle_cfg(decode_type, code.R), depunctured[f], TOTAL_DATA_BITS)
+        assert np.array_equal(out[f], want["bytes"]), f
+    # ragged tail: a symbol count that is not a multiple of the 8-symbol store width, odd frame offsets for 8-bit symbols
+    short = np.ones(5 * code.R, dtype=bool)
+    short[[1, 6, 7, 13]] = False
+    src = np.ascontiguousarray(flat[:, : int(short.sum())])
+    got = dec.depuncture(torch.from_numpy(src).cuda(), short).cpu().numpy().reshape(F, -1)
+    ref = np.zeros((F, short.size), dtype=flat.dtype)
+    ref[:, short] = src
+    assert np.array_equal(got, ref)

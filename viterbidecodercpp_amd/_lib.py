@@ -21,7 +21,7 @@ EXPORTS = [
     "vit_hip_last_error", "vit_hip_device_count", "vit_hip_create", "vit_hip_destroy", "vit_hip_get_info",
     "vit_hip_set_plan", "vit_hip_blob_bytes", "vit_hip_pack_blob", "vit_hip_create_from_blob",
     "vit_hip_workspace_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
-    "vit_hip_export_decisions", "vit_hip_update_host", "vit_hip_chainback_host",
+    "vit_hip_export_decisions", "vit_hip_depuncture_batch", "vit_hip_update_host", "vit_hip_chainback_host",
 ]
 
 
@@ -71,6 +71,7 @@ def load():
     L.vit_hip_chainback_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.vit_hip_decode_batch.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, vp, vp, vp]
     L.vit_hip_export_decisions.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    L.vit_hip_depuncture_batch.argtypes = [vp, vp, sz, vp, sz, sz, vp, vp]
     L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     L.vit_hip_chainback_host.argtypes = [vp, vp, sz, sz, vp]
     _lib = L

@@ -196,6 +196,40 @@ unsigned parity_u32(uint32_t x) { return (unsigned)__builtin_popcount(x) & 1u; }
 
 }  // namespace
 
+namespace vit {
+// depuncturing gather (examples/helpers/puncture_code_helpers.h:17-55 for a batch): out[f][k] = in[f][idx[k]] or 0.  One
+// thread makes 8 consecutive output symbols of one frame (16-byte / 8-byte store); the index map is read once per 8 symbols
+// as two 16-byte loads and stays in L2; source reads are consecutive because the map is monotonic.
+template <typename T>
+__global__ void depuncture_kernel(const T* __restrict__ in, size_t in_stride, const int32_t* __restrict__ idx, size_t n_out,
+                                  size_t frames, T* __restrict__ out) {
+    const size_t chunks = (n_out + 7) / 8;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= chunks * frames) return;
+    const size_t f = gid / chunks, k0 = (gid % chunks) * 8;
+    const T* src = in + f * in_stride;
+    T* dst = out + f * n_out + k0;
+    T v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t k = k0 + i;
+        const int32_t j = k < n_out ? idx[k] : -1;
+        v[i] = j >= 0 ? src[j] : (T)0;
+    }
+    if (k0 + 8 <= n_out && ((uintptr_t)dst % (8 * sizeof(T))) == 0) {
+        typedef T vec8 __attribute__((ext_vector_type(8)));
+        vec8 w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = v[i];
+        *(vec8*)dst = w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k0 + i < n_out) dst[i] = v[i];
+    }
+}
+}  // namespace vit
+
 extern "C" {
 
 const char* vit_hip_last_error(void) { return g_last_error.c_str(); }
@@ -458,6 +492,30 @@ int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t f
     const size_t W8 = (size_t)h->W * 8;
     VIT_HIP_CHECK(hipMemcpy2DAsync(d_decisions, n_steps * W8, d_workspace, rows * W8, n_steps * W8, frames,
                                    hipMemcpyDeviceToDevice, st));
+    return VIT_HIP_OK;
+}
+
+int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t punctured_per_frame,
+                             const int32_t* d_source_index, size_t symbols_per_frame, size_t frames, void* d_symbols_out,
+                             vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0 || symbols_per_frame == 0) return VIT_HIP_OK;
+    if (!d_punctured || !d_source_index || !d_symbols_out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL buffer");
+    if (symbols_per_frame % (size_t)h->R != 0)
+        return fail(VIT_HIP_ERR_INVALID_ARG, "symbols_per_frame must be a multiple of the code rate R");
+    const size_t chunks = (symbols_per_frame + 7) / 8;
+    if (chunks * frames > 0x7FFFFFFFull * 256ull) return fail(VIT_HIP_ERR_INVALID_ARG, "batch too large for one launch");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((chunks * frames + 255) / 256);
+    if (h->soft_bytes == 2)
+        hipLaunchKernelGGL(vit::depuncture_kernel<int16_t>, dim3(blocks), dim3(256), 0, st, (const int16_t*)d_punctured,
+                           punctured_per_frame, d_source_index, symbols_per_frame, frames, (int16_t*)d_symbols_out);
+    else
+        hipLaunchKernelGGL(vit::depuncture_kernel<int8_t>, dim3(blocks), dim3(256), 0, st, (const int8_t*)d_punctured,
+                           punctured_per_frame, d_source_index, symbols_per_frame, frames, (int8_t*)d_symbols_out);
+    VIT_HIP_CHECK(hipGetLastError());
     return VIT_HIP_OK;
 }
 

@@ -307,6 +307,29 @@ class BatchDecoder:
             C.c_void_p(rs.data_ptr()) if rs is not None else None, None, self._stream()))
         return (out, met, rs) if want_metrics else out
 
+    def depuncture(self, punctured, mask, out=None):
+        """Depuncturing front-end (examples/helpers/puncture_code_helpers.h:17-55) for a batch: `punctured` is the device
+        tensor [F][P] of transmitted symbols, `mask` the puncturing vector over one whole frame (truthy = transmitted, one
+        entry per mother-code symbol, S*R in all); returns [F][S][R] with 0 (erasure) at the punctured positions."""
+        t = self.torch
+        mask = np.asarray(mask).astype(bool).reshape(-1)
+        if mask.size % self.R != 0:
+            raise ValueError("the puncturing vector must cover whole trellis steps (a multiple of R symbols)")
+        if not (punctured.is_cuda and punctured.dim() == 2 and punctured.is_contiguous()):
+            raise ValueError("punctured symbols must be a contiguous [frames][P] device tensor")
+        sdt = t.int16 if self.soft_bytes == 2 else t.int8
+        if punctured.dtype != sdt or punctured.shape[1] != int(mask.sum()):
+            raise ValueError("punctured symbols: wrong dtype or count for this puncturing vector")
+        idx = np.where(mask, np.cumsum(mask) - 1, -1).astype(np.int32)
+        d_idx = t.from_numpy(idx).to(self.device)
+        frames = punctured.shape[0]
+        if out is None:
+            out = t.empty((frames, mask.size // self.R, self.R), dtype=sdt, device=self.device)
+        _lib.check(_lib.load().vit_hip_depuncture_batch(self._handle._h, C.c_void_p(punctured.data_ptr()), punctured.shape[1],
+                                                        C.c_void_p(d_idx.data_ptr()), mask.size, frames,
+                                                        C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def export_decisions(self, frames: int, L: int, n_steps: int = None):
         """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words)."""
         t = self.torch
