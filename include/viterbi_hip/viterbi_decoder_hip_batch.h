@@ -53,6 +53,13 @@ public:
         check(vit_hip_chainback_batch(m_hip, d_workspace, frames, total_bits, d_bytes_out, d_end_state, stream),
               "vit_hip_chainback_batch");
     }
+    // depuncturing front-end (examples/helpers/puncture_code_helpers.h:17-55 for a batch): d_source_index[k] is the position of
+    // mother-code symbol k among the `punctured_per_frame` transmitted ones, or < 0 for a punctured symbol (erasure value 0)
+    void depuncture(const soft_t* d_punctured, size_t punctured_per_frame, const int32_t* d_source_index, size_t frames,
+                    size_t total_bits, soft_t* d_symbols_out, void* stream = nullptr) {
+        check(vit_hip_depuncture_batch(m_hip, d_punctured, punctured_per_frame, d_source_index, symbols_per_frame(total_bits),
+                                       frames, d_symbols_out, stream), "vit_hip_depuncture_batch");
+    }
     vit_hip_handle hip_handle() const { return m_hip; }
 
 private:
