@@ -133,3 +133,15 @@ def test_lds2_block_boundaries_and_mid_block_renormalisation(oracle):
                 assert np.array_equal(met[f].astype(np.uint32), want[f]["metrics"]), (width, thr, f)
                 assert int(rs[f].item()) == want[f]["renorm_sum"], (width, thr, f)
                 assert np.array_equal(out[f], want[f]["bytes"]), (width, thr, f)
+
+
+@pytest.mark.parametrize("code_id,F,L", [(2, 70, 4104), (2, 33, 2056), (5, 35, 2600), (5, 5, 1032)])
+def test_long_frames_chainback_flushes(oracle, code_id, F, L):
+    """The K = 7 / K = 9 chainback kernels park output bytes in LDS and flush them every 1024 steps: frames long enough for
+    several flushes, lengths that leave a partial last flush and byte offsets that are not dword aligned, non-zero end
+    states, frame counts that leave partial tiles."""
+    code = COMMON_CODES[code_id]
+    rng = np.random.default_rng(L)
+    es = rng.integers(0, code.num_states, F).astype(np.int32)
+    check_batch_against_oracle(oracle, code, "SOFT16", F, L, 2.0, seed=L + 1, end_state=es)
+    check_batch_against_oracle(oracle, code, "HARD8", F, L + 8, 5.0, seed=L + 2)
