@@ -226,7 +226,9 @@ def main():
         "update_ms": upd_ms, "chainback_ms": cb_ms,
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": upd_bytes},
+                     "algorithmic_bytes_per_launch": upd_bytes,
+                     "limiter": "integer VALU issue, not HBM: the kernel's measured HBM bytes equal the algorithmic bytes "
+                                "(traffic) and its waves issue VALU back to back (DESIGN.md 4.4, profiles/*_summary.md)"},
         "roofline_end_to_end": {"achieved": (upd_bytes + cb_bytes) / ((upd_ms + cb_ms) * 1e-3) / 1e9, "unit": "GB/s",
                                 "bytes_per_info_bit": (upd_bytes + cb_bytes) / float(F * L)},
         "ber": ber,
