@@ -17,9 +17,10 @@
 //     lane bits, one v_permlane32_swap / v_permlane16_swap per register pair exchanges that lane bit with the top
 //     register bit before the butterflies and again after them (2 of every K-1 steps).
 //   * branch metrics: the convolutional code is linear, so the R-bit branch pattern of butterfly (q, r) is
-//     pat(r) ^ pat(q); pat(r) is a compile-time constant per register and pat(q) is folded in by giving every lane its own
-//     (phase, polynomial) copies of high/low.  Only 2^R packed error sums E[p] (and max_error - E[p]) exist per step, and
-//     those of step t+1 are computed inside step t's basic block (software pipelining).
+//     pat(r) ^ pat(q); pat(r) is a compile-time constant per register.  Only 2^R packed error sums E[p] (and
+//     max_error - E[p]) exist per frame pair and step.  K = 7, 9: the four q-lanes of a pair SHARE that work through an LDS
+//     ring -- in every group of 4 steps lane (q, g) computes the sums of step 4J+q once, and every step each lane reads
+//     E[p ^ pat(q)] through per-lane addresses (LDSBM in reg_update_body).  K = 3, 5: computed in the lane, one step ahead.
 //   * add-compare-select per register pair, 8 packed instructions, exact for wrapping u16 metrics: metrics are kept
 //     biased (m ^ 0x8000) so the reference's unsigned compare is a signed one; new = v_pk_min_i16(x, y); the decision is
 //     the SIGN of v_pk_sub_i16(y, x) with clamp -- saturation keeps the sign exact at any distance, a tie gives 0 (the
@@ -30,9 +31,11 @@
 //     dword per 16 registers: byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B registers 8-15.  Stored as coalesced
 //     16-byte-per-lane rows ws[tile][step group][lane] (1 KiB per wave store).  Bit order is the slot order of the step
 //     (a rotation of the state index) -- vit_hip_export_decisions() converts to the reference's bit order.
-//   * chainback: K = 7 and K <= 5 use one lane per frame with everything on the dependent chain lane-local
-//     (reg_chainback16_kernel / reg_chainback0_kernel); K = 9 keeps the update kernel's lane roles, each q-lane extracts
-//     the candidate bit of its slice and a ds_bpermute fetches the survivor's (reg_chainback_kernel).
+//   * chainback: K = 7 uses one lane per frame PAIR and K <= 5 one lane per frame, with everything on the dependent chain
+//     lane-local (reg_chainback16_body / reg_chainback0_body); K = 9 keeps the update kernel's lane roles, each q-lane
+//     extracts the candidate bit of its slice and a ds_bpermute fetches the survivor's (reg_chainback_coop_body).  The
+//     row rings of K = 7, 9 keep counted vmcnt waits because no store is pending inside their loops: output bytes are
+//     parked in LDS and flushed every 1024 steps.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
