@@ -134,6 +134,70 @@ KERNEL(k_n_min3_32, A_MIN3_32)
 KERNEL(k_n_sad8, A_SAD8)
 KERNEL(k_n_dot4, A_DOT4)
 KERNEL(k_n_addco, A_ADDCO)
+
+#define A_MIX_PK_AND(i)  "v_pk_add_u16 %" #i ", %" #i ", %8\nv_and_b32 %" #i ", %8, %" #i "\n"
+#define A_MIX_PK_PK(i)   "v_pk_add_u16 %" #i ", %" #i ", %8\nv_pk_min_i16 %" #i ", %" #i ", %8\n"
+#define A_MIX_AND_AND(i) "v_and_b32 %" #i ", %8, %" #i "\nv_or_b32 %" #i ", %8, %" #i "\n"
+#define A_MIX_PK_AND2(i) "v_pk_add_u16 %" #i ", %" #i ", %8\nv_and_b32 %" #i ", %8, %" #i "\nv_or_b32 %" #i ", %8, %" #i "\n"
+KERNEL(k_mix_pk_and, A_MIX_PK_AND)
+KERNEL(k_mix_pk_pk, A_MIX_PK_PK)
+KERNEL(k_mix_and_and, A_MIX_AND_AND)
+KERNEL(k_mix_pk_and2, A_MIX_PK_AND2)
+
+#define KERNEL_RAW(NAME, BODY)                                                                     \
+__global__ void NAME(uint32_t* out, uint32_t seed) {                                               \
+    uint32_t v0 = threadIdx.x + seed, v1 = v0 * 3, v2 = v0 * 5, v3 = v0 * 7, v4 = v0 * 11, v5 = v0 * 13, v6 = v0 * 17, v7 = v0 * 19; \
+    uint32_t c = seed | 0x00010001u;                                                               \
+    for (int it = 0; it < ITER; ++it) {                                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                            \
+            asm volatile(BODY                                                                      \
+                : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(c)); \
+        }                                                                                          \
+    }                                                                                              \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7;            \
+}
+KERNEL_RAW(k_imix_pk_and,
+        "v_pk_add_u16 %0, %0, %8\n"
+        "v_and_b32 %4, %8, %4\n"
+        "v_pk_add_u16 %1, %1, %8\n"
+        "v_and_b32 %5, %8, %5\n"
+        "v_pk_add_u16 %2, %2, %8\n"
+        "v_and_b32 %6, %8, %6\n"
+        "v_pk_add_u16 %3, %3, %8\n"
+        "v_and_b32 %7, %8, %7\n"
+        "v_pk_add_u16 %4, %4, %8\n"
+        "v_and_b32 %0, %8, %0\n"
+        "v_pk_add_u16 %5, %5, %8\n"
+        "v_and_b32 %1, %8, %1\n"
+        "v_pk_add_u16 %6, %6, %8\n"
+        "v_and_b32 %2, %8, %2\n"
+        "v_pk_add_u16 %7, %7, %8\n"
+        "v_and_b32 %3, %8, %3\n")
+KERNEL_RAW(k_imix_pk_and_or,
+        "v_pk_add_u16 %0, %0, %8\n"
+        "v_and_b32 %4, %8, %4\n"
+        "v_or_b32 %6, %8, %6\n"
+        "v_pk_add_u16 %1, %1, %8\n"
+        "v_and_b32 %5, %8, %5\n"
+        "v_or_b32 %7, %8, %7\n"
+        "v_pk_add_u16 %2, %2, %8\n"
+        "v_and_b32 %6, %8, %6\n"
+        "v_or_b32 %0, %8, %0\n"
+        "v_pk_add_u16 %3, %3, %8\n"
+        "v_and_b32 %7, %8, %7\n"
+        "v_or_b32 %1, %8, %1\n"
+        "v_pk_add_u16 %4, %4, %8\n"
+        "v_and_b32 %0, %8, %0\n"
+        "v_or_b32 %2, %8, %2\n"
+        "v_pk_add_u16 %5, %5, %8\n"
+        "v_and_b32 %1, %8, %1\n"
+        "v_or_b32 %3, %8, %3\n"
+        "v_pk_add_u16 %6, %6, %8\n"
+        "v_and_b32 %2, %8, %2\n"
+        "v_or_b32 %4, %8, %4\n"
+        "v_pk_add_u16 %7, %7, %8\n"
+        "v_and_b32 %3, %8, %3\n"
+        "v_or_b32 %5, %8, %5\n")
 KERNEL(k_cnds, A_CNDS)
 KERNEL(k_bfi, A_BFI)
 KERNEL(k_andor, A_ANDOR)
@@ -240,6 +304,9 @@ int main() {
         {"sad8", k_n_sad8, 1},
         {"dot4", k_n_dot4, 1},
         {"addco", k_n_addco, 1},
+        {"mix pk_add+and (per pair)", k_mix_pk_and, 1}, {"mix pk_add+pk_min (per pair)", k_mix_pk_pk, 1},
+        {"mix and+or (per pair)", k_mix_and_and, 1}, {"mix pk_add+and+or (per triple)", k_mix_pk_and2, 1},
+        {"indep mix pk_add+and (per pair)", k_imix_pk_and, 1}, {"indep mix pk+and+or (per triple)", k_imix_pk_and_or, 1},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
