@@ -77,6 +77,12 @@ VIT_DEV u32 pk_sub_sat_s(u32 a, u32 b) {
     asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// the same with a wave-uniform first operand taken straight from an SGPR (no v_mov)
+VIT_DEV u32 pk_sub_sat_s_uniform(u32 a_uniform, u32 b) {
+    u32 d;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "s"(a_uniform), "v"(b));
+    return d;
+}
 
 template <class F, int... Is>
 VIT_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
@@ -424,6 +430,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     }
 
     u32 t0 = 0;
+    uint4* ws_blk = ws_tile;   // wave-uniform: decision rows of the current block (U is a multiple of SPS)
     // one unrolled block of U trellis steps; `guarded` adds the per-step bound check needed only by the last, partial block
     auto block = [&](auto guarded_c) __attribute__((always_inline)) {
         constexpr bool GUARDED = decltype(guarded_c)::value;
@@ -495,7 +502,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     D[r1] = pk_sub_sat_s(y1, x1);
                 });
                 // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
-                const u32 need = (pk_sub_sat_s(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
+                const u32 need = (pk_sub_sat_s_uniform(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
                 // ---- gather the 2 x NREG sign bits.  v_perm_b32 selectors 8..11 replicate the sign of a 16-bit half over a
                 //      whole byte, so one perm of the register pair (r, r+8) yields four CLEAN bytes (0x00 / 0xFF):
                 //      {A r, B r, A r+8, B r+8}; pair j then drops into bit j of every byte with a single v_and_or (no shift
@@ -509,22 +516,19 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         constexpr int rr = decltype(rc)::value;
                         if constexpr (rr < NREG) return D[rr]; else return 0u;
                     };
-                    // two independent 4-deep chains instead of one 8-deep
-                    u32 lo4 = 0, hi4 = 0;
+                    // ONE chain: 8 perms + 1 and + 7 and_or (a second chain would cost a join; the chain's latency hides behind
+                    // the other wave and the next step's adds)
+                    u32 ch = 0;
                     static_for<4>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         constexpr int r = 16 * d + k;
                         const u32 pl = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), SIGN_BYTES);
                         const u32 ph = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), SIGN_BYTES);
-                        if constexpr (k == 0) {
-                            lo4 = pl & 0x01010101u;
-                            hi4 = ph & 0x10101010u;
-                        } else {
-                            lo4 = and_or(pl, 0x01010101u << k, lo4);
-                            hi4 = and_or(ph, 0x10101010u << k, hi4);
-                        }
+                        if constexpr (k == 0) ch = pl & 0x01010101u;
+                        else ch = and_or(pl, 0x01010101u << k, ch);
+                        ch = and_or(ph, 0x10101010u << k, ch);
                     });
-                    acc[d] = lo4 | hi4;
+                    acc[d] = ch;
                 });
                 if constexpr (LP && NREG == 16) {
                     // registers 0-7 / 8-15 (low / high half of the dword) belong to different lanes until the exchange is
@@ -547,18 +551,18 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 }
                 // ---- decision rows: 16 bytes per lane, 1 KiB per wave, coalesced ----
                 if constexpr (DW == 4) {
-                    ws_tile[(size_t)(t0 + u) * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                    ws_blk[u * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
                 } else {
                     static_for<DW>([&](auto dc) __attribute__((always_inline)) {
                         constexpr int d = decltype(dc)::value;
                         dq[(u % SPS) * DW + d] = acc[d];
                     });
                     if constexpr (u % SPS == SPS - 1)
-                        ws_tile[(size_t)((t0 + u) / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                        ws_blk[(u / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
                 }
                 // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153); state 0 is slot 0 ----
                 {
-                    const u32 need2 = LP ? ((pk_sub_sat_s(THRM1B2, m[0]) | FORCE) & MASKQ) : need;
+                    const u32 need2 = LP ? ((pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & MASKQ) : need;
                     if (__builtin_amdgcn_ballot_w64(need2 != 0) != 0) {
                         const u32 nq = SP::LANE_BITS ? (u32)__shfl((int)need2, (int)g) : need2;
                         const u32 msk = ((nq & 0x8000u) ? 0x0000FFFFu : 0u) | ((nq & 0x80000000u) ? 0xFFFF0000u : 0u);
@@ -582,7 +586,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             }
         });
     };
-    for (; t0 + U <= a.n_steps; t0 += U) block(std::false_type{});
+    for (; t0 + U <= a.n_steps; t0 += U, ws_blk += (U / SPS) * 64) block(std::false_type{});
     if (t0 < a.n_steps) block(std::true_type{});
 
     if constexpr (DW != 4) {
