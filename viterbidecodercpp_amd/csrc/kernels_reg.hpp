@@ -906,20 +906,41 @@ VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
         for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(g_top - b) * 64];
         int gb = g_top;
         u32 ph = (u32)((4 * gb + 3 + 1) % SB);
-        for (; gb - (NBUF - 1) >= g_min; gb -= NBUF) {
+        // as in reg_chainback16_body: no store inside the ring loop (it would force vmcnt(0) at every loop top); the 4 bytes
+        // of an iteration are assembled in a register, parked in LDS and flushed as one dword store every KI iterations
+        constexpr int KI = 32;
+        __shared__ u32 obuf[KI * 64];
+        typedef u32 u32_unaligned __attribute__((aligned(1)));
+        while (gb - (NBUF - 1) >= g_min) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): retire the previous flush (and the ring)
+            const int gb0 = gb;
+            int it = 0;
+            for (; it < KI && gb - (NBUF - 1) >= g_min; ++it, gb -= NBUF) {
+                u32 acc = 0;
 #pragma unroll
-            for (int b = 0; b < NBUF; ++b) {
-                const int grp = gb - b;                         // parity == parity of b (gb is even)
+                for (int b = 0; b < NBUF; ++b) {
 #pragma unroll
-                for (int sidx = 3; sidx >= 0; --sidx) {
-                    const u32 w = sidx == 0 ? buf[b].x : sidx == 1 ? buf[b].y : sidx == 2 ? buf[b].z : buf[b].w;
-                    chase(w, ph);
-                    ph = ph == 0 ? SB - 1 : ph - 1;
-                    if ((b & 1) == OUT_PAR && sidx == OUT_SIDX) out[(u32)(4 * grp + sidx - SB) >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
+                    for (int sidx = 3; sidx >= 0; --sidx) {
+                        const u32 w = sidx == 0 ? buf[b].x : sidx == 1 ? buf[b].y : sidx == 2 ? buf[b].z : buf[b].w;
+                        chase(w, ph);
+                        ph = ph == 0 ? SB - 1 : ph - 1;
+                        // byte (4*grp + sidx - SB)/8 is complete; bytes come out in descending order
+                        if ((b & 1) == OUT_PAR && sidx == OUT_SIDX) acc = (acc << 8) | ((reg >> SHIFT_TAIL) & 0xFFu);
+                    }
+                    asm volatile("" : "+v"(reg) : : "memory");   // pin the chase of this group in front of its refill
+                    const int nxt = gb - b - NBUF;
+                    buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                const int nxt = grp - NBUF;
-                buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
-                __builtin_amdgcn_sched_barrier(0);
+                obuf[it * 64 + lane] = acc;
+            }
+            // iteration i started at group G = gb0 - NBUF*i (even); its LAST completed byte is that of the lowest group with
+            // parity OUT_PAR: grp = G - 7 + ((OUT_PAR + 1) & 1) ... computed directly from the emit rule below
+            for (int i = 0; i < it; ++i) {
+                const int G = gb0 - NBUF * i;
+                const int grp_last = G - (NBUF - 1) + ((OUT_PAR ^ 1) & 1);       // lowest group of the iteration with (b & 1) == OUT_PAR
+                const u32 jb = (u32)(4 * grp_last + OUT_SIDX - SB) >> 3;         // lowest of the 4 bytes
+                *(u32_unaligned*)(out + jb) = obuf[i * 64 + lane];
             }
         }
         t = 4 * gb + 3;
