@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     uint2* const etab = (uint2*)lds2_smem;                     // [2][BLK][64] {E, max_error - E}
     u32* const wmin = (u32*)(etab + 2 * BLK * 64);             // [16]
     u32* const flag = wmin + 16;                               // [2] mid-block renormalisation seen by thread 0; [2] scratch
+    uint64_t* const rs_acc = (uint64_t*)(flag + 8);            // [2] sum of subtracted minima, frame A / B (thread 0 only)
     u32* const met = flag + 16;                                // [2][N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             const u32 hi = ((u32)s == sB) ? a.cfg.init_start : a.cfg.init_non_start;
             met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
         }
-        if (tid < 4) flag[tid] = 0;
+        if (tid < 16) flag[tid] = 0;          // flags and the two 64-bit renormalisation sums
     }
 
     // ---- branch-metric table builder: lane p makes entry p of the table of one step ----
@@ -231,7 +232,6 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     tables_load(BLK);
     __syncthreads();
 
-    uint64_t rsA = 0, rsB = 0;
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
     u32 m[16];
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
         // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
         constexpr u32 SIGN_BYTES = 0x0b0a0908u;
-        u32 lo4 = 0, hi4 = 0;
+        u32 lo4 = 0;
         l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value;
             constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
@@ -255,12 +255,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             const u32 d0 = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
             const u32 d1 = l2_sub_sat_s(y1, x1);
             const u32 sg = __builtin_amdgcn_perm(d1, d0, SIGN_BYTES);
+            // one chain: 1 and + 7 and_or (a second chain would cost a join)
             if constexpr (h == 0) lo4 = sg & 0x01010101u;
-            else if constexpr (h == 1) hi4 = sg & 0x02020202u;
-            else if constexpr (h % 2 == 0) lo4 = l2_and_or(sg, 0x01010101u << h, lo4);
-            else hi4 = l2_and_or(sg, 0x01010101u << h, hi4);
+            else lo4 = l2_and_or(sg, 0x01010101u << h, lo4);
         });
-        wsp[C * T + tid] = lo4 | hi4;
+        wsp[C * T + tid] = lo4;
     };
     // swizzled metric buffers (lds2_sw): read view, register r = state r*T + j; write view, piece q = states 16 j + 4 q ...
     constexpr bool SEP = (T / 16) % 8 == 0;     // r*T/16 does not reach the three bits the swizzle touches: base + r*T/4
@@ -292,8 +291,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
 #pragma unroll
         for (int i = 0; i < 16; ++i) m[i] = l2_sub(m[i], sub);
-        rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
-        rsB += (uint64_t)((sub >> 16) >> SHIFT);
+        if (tid == 0) {                       // update()'s return value: kept in LDS, not in four VGPRs of every thread
+            rs_acc[0] += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
+            rs_acc[1] += (uint64_t)((sub >> 16) >> SHIFT);
+        }
         __syncthreads();                      // wmin may be rewritten by the next reduction
     };
     // the careful version of a block: `nst` stages (1..4) with the threshold test and the reduction after EVERY stage; used
@@ -301,6 +302,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     auto slow_block = [&](u32 t0, int buf, int nst) __attribute__((always_inline)) {
         const u32* src = met + buf * N;
         u32* dst = met + (buf ^ 1) * N;
+        // an opaque copy of the thread index: the 3 x 16 scatter addresses of the partial-block write-back below are loop
+        // invariant, and hoisted out of the main loop they cost the FAST path its registers (spills) for a once-per-frame use
+        u32 tid_o = (u32)tid;
+        asm volatile("" : "+v"(tid_o));
         load_metrics(src);
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
@@ -318,7 +323,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
                     } else {
                         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
                             constexpr u32 r = decltype(rc)::value;
-                            dst[lds2_sw(lds2_state_of(C, r, (u32)tid, SBITS), (u32)N)] = m[r];
+                            dst[lds2_sw(lds2_state_of(C, r, tid_o, SBITS), (u32)N)] = m[r];
                         });
                     }
                 }
@@ -383,8 +388,8 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         }
     }
     if (a.renorm_sum && tid == 0) {
-        a.renorm_sum[fA] = rsA;
-        if (validB) a.renorm_sum[fB] = rsB;
+        a.renorm_sum[fA] = rs_acc[0];
+        if (validB) a.renorm_sum[fB] = rs_acc[1];
     }
 }
 
