@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised soak on the GPU box: tests/test_gpu_fuzz.py's comparison (decision words, metrics, renormalisation sums,
+chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  usage: soak_fuzz.py [seconds] [first_seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from oracle import pyoracle
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib
+from tests.test_gpu_fuzz import random_config
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pyoracle.ensure_built()
+oracle = pyoracle.Oracle()
+CASES = [(COMMON_CODES[2], [_lib.PLAN_REG]), (COMMON_CODES[3], [_lib.PLAN_REG]), (COMMON_CODES[4], [_lib.PLAN_REG]),
+         (COMMON_CODES[5], [_lib.PLAN_REG]), (COMMON_CODES[6], [_lib.PLAN_REG]), (COMMON_CODES[0], [_lib.PLAN_REG]),
+         (COMMON_CODES[1], [_lib.PLAN_REG]), (Code("K11", 11, 2, (0o3345, 0o3613)), [_lib.PLAN_LDS2]),
+         (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), [_lib.PLAN_LDS2]), (COMMON_CODES[7], [_lib.PLAN_LDS2])]
+t_end = time.time() + budget
+n = 0
+while time.time() < t_end:
+    for ci, (code, plans) in enumerate(CASES):
+        for width in (2, 1):
+            rng = np.random.default_rng(100000 * seed + 10 * ci + width)
+            trial = int(rng.integers(0, 4))
+            cfg = random_config(rng, width, trial)
+            sdt = np.int16 if width == 2 else np.int8
+            table = ViterbiBranchTable(code.K, code.R, code.G, cfg.high, cfg.low, sdt)
+            config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
+                                           cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
+            F = int(rng.integers(1, 70)) if code.K < 11 else int(rng.integers(1, 5))
+            L = int(rng.integers(1, 200)) if code.K < 11 else (int(rng.integers(1, 60)) if code.K < 15 else int(rng.integers(1, 24)))
+            S = L + code.K - 1
+            lim = 1 << (8 * width - 1)
+            if rng.integers(0, 2):
+                sym = rng.integers(cfg.low, cfg.high + 1, size=(F, S, code.R)).astype(sdt)
+            else:
+                sym = rng.integers(-lim, lim, size=(F, S, code.R)).astype(sdt)
+            N = code.num_states
+            ss = rng.integers(0, N, F).astype(np.int32)
+            es = rng.integers(0, N, F).astype(np.int32)
+            want = [oracle.decode(code.K, code.R, code.G, cfg, sym[f], L, start_state=int(ss[f]), end_state=int(es[f])) for f in range(F)]
+            d_sym = torch.from_numpy(sym).cuda()
+            for plan in plans:
+                dec = BatchDecoder(table, config, plan=plan)
+                met, rs = dec.update(d_sym, L, start_state=ss)
+                got_dec = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
+                out = dec.chainback(F, L, end_state=es).cpu().numpy()
+                met = met.cpu().numpy()
+                met = met.view(np.uint16) if width == 2 else met
+                for f in range(F):
+                    tag = (seed, code.name, plan, width, f, L, cfg)
+                    assert np.array_equal(got_dec[f], want[f]["decisions"]), ("decisions", tag)
+                    assert np.array_equal(met[f].astype(np.uint32), want[f]["metrics"]), ("metrics", tag)
+                    assert int(rs[f].item()) == want[f]["renorm_sum"], ("renorm", tag)
+                    assert np.array_equal(out[f], want[f]["bytes"]), ("bytes", tag)
+            n += 1
+    seed += 1
+print(f"soak ok: {n} random (code, width, config) cases, last seed {seed - 1}")
