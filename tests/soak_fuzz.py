@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak on the GPU box: tests/test_gpu_fuzz.py's comparison (decision words, metrics, renormalisation sums,
-chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  usage: soak_fuzz.py [seconds] [first_seed]"""
+chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  usage: python tests/soak_fuzz.py [seconds] [first_seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
