@@ -320,8 +320,13 @@ class BatchDecoder:
         sdt = t.int16 if self.soft_bytes == 2 else t.int8
         if punctured.dtype != sdt or punctured.shape[1] != int(mask.sum()):
             raise ValueError("punctured symbols: wrong dtype or count for this puncturing vector")
-        idx = np.where(mask, np.cumsum(mask) - 1, -1).astype(np.int32)
-        d_idx = t.from_numpy(idx).to(self.device)
+        key = mask.tobytes()
+        cached = getattr(self, "_depuncture_map", None)
+        if cached is None or cached[0] != key:             # the map is per puncturing scheme: build and upload it once
+            idx = np.where(mask, np.cumsum(mask) - 1, -1).astype(np.int32)
+            cached = (key, t.from_numpy(idx).to(self.device))
+            self._depuncture_map = cached
+        d_idx = cached[1]
         frames = punctured.shape[0]
         if out is None:
             out = t.empty((frames, mask.size // self.R, self.R), dtype=sdt, device=self.device)
