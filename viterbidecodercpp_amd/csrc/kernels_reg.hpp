@@ -211,9 +211,12 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // LDS ring, in steps: the slot of step t is t % RING, a compile-time constant because RING divides the block length; 16 KiB
     // per wave at most, so that eight waves still fit a CU (R = 4 with 6 state bits: 8 steps, block of 24)
     constexpr int RING = !LDSBM ? 1 : (U0 * NP * 128 <= 16384 ? U0 : 8);
-    constexpr int U = LDSBM ? clcm(U0, RING) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
+    // the 16-register codes (K = 7) unroll two periods (24 steps) so that the symbol ring below can run six groups ahead
+    constexpr int U = LDSBM ? clcm(clcm(U0, RING), NREG == 16 ? 24 : 1) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
     constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
-    constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 3 == 0 ? 3 : 2);   // depth of the symbol register ring, in groups
+    // depth of the symbol register ring, in groups of 4 steps (a divisor of the block): 6 groups = 24 steps of load latency
+    // hidden for K = 7 (+1 % alone and overlapped over 3 groups), 2 for K = 9 (a step is four times longer there)
+    constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : 2);
     constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
     static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
     constexpr bool RDTAB = SB * NP <= 32;         // read indices per (phase, pattern) in registers; else per phase + one v_xor per read
