@@ -846,7 +846,7 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
                     asm volatile("" : "+v"(regA), "+v"(regB) : : "memory");
                     const int nxt = grp - NBUF;
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16];
+                    for (int qq = 0; qq < 4; ++qq) { typedef u32 u32x4_t __attribute__((ext_vector_type(4))); const u32x4_t v4 = __builtin_nontemporal_load((const u32x4_t*)&rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16]); buf[b][qq] = make_uint4(v4.x, v4.y, v4.z, v4.w); }
                     // keep the refill where it is written: hipcc otherwise sinks/merges the loads and the ring loses its depth
                     __builtin_amdgcn_sched_barrier(0);
                 }
