@@ -403,7 +403,12 @@ struct Lds2ChainbackArgs {
     int32_t K;
 };
 
-// one lane per frame; the decision dword of (step t, next-state s): ws[pair][t][j], bit of register r -- lds2_locate()
+// one lane per frame; the decision dword of (step t, next-state s): ws[pair][t][j], bit of register r -- lds2_locate().
+// The chase is a chain of dependent loads (the dword index j is a slice of the state), but only partly: thread index j of
+// step t uses state bits [nlow, nlow + K-5) with nlow = t%4 + 1, and going k steps back leaves the low K-1-k bits of the
+// state known.  Starting from a step with t%4 == 3 the addresses of steps t, t-1, t-2, t-3 all follow from state_t alone
+// (their slices end below the bits that are still to be decoded), so the four loads are issued together and the four bits
+// are resolved from registers: ONE memory round trip per four steps instead of four.
 __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     const size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.frames) return;
@@ -415,15 +420,41 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     const u32 half = (u32)(f & 1);
     uint8_t* out = a.out + f * (((size_t)a.L + 7) / 8);
     u32 reg = (a.end_state ? (a.end_state[f] & ((1u << TSB) - 1u)) : 0u) << shift_state;
-    for (size_t j = a.L; j-- > 0;) {
+    const u32 jmask = T - 1u;
+    auto step = [&](size_t j, u32 w) {               // resolve decoded bit j from the already loaded dword of step j + TSB
         const u32 state = reg >> shift_state;
         const u32 t = (u32)(j + (size_t)TSB);
         u32 tj, r;
         lds2_locate(state, t, TSB, tj, r);
-        const u32 w = ws[(size_t)t * T + tj];
         const u32 bit = (w >> lds2_dec_bit(r, half, t & 3u)) & 1u;
         reg = (reg >> 1) | (bit << (total_bits - 1));
         if ((j & 7) == 0) out[j >> 3] = (uint8_t)((reg >> shift_tail) & 0xFFu);
+    };
+    auto load = [&](size_t j, u32 state_j) -> u32 {  // dword of step j + TSB for a survivor whose (known part of the) state is state_j
+        const u32 t = (u32)(j + (size_t)TSB);
+        const u32 nlow = (t & 3u) + 1u;
+        return ws[(size_t)t * T + ((state_j >> nlow) & jmask)];
+    };
+    size_t j = a.L;
+    // ragged top: single dependent steps down to a step with t % 4 == 3
+    while (j > 0 && (((j - 1 + (size_t)TSB) & 3) != 3)) {
+        --j;
+        step(j, load(j, reg >> shift_state));
+    }
+    // blocks of four steps: t = j-1+TSB has t % 4 == 3
+    while (j >= 4) {
+        const u32 s0 = reg >> shift_state;
+        // state k steps back = (s0 >> k) | (newest k bits on top): the slice of step t-k ends at bit (4-k) + K-6 < K-1-k
+        const u32 w0 = load(j - 1, s0), w1 = load(j - 2, s0 >> 1), w2 = load(j - 3, s0 >> 2), w3 = load(j - 4, s0 >> 3);
+        step(j - 1, w0);
+        step(j - 2, w1);
+        step(j - 3, w2);
+        step(j - 4, w3);
+        j -= 4;
+    }
+    while (j > 0) {
+        --j;
+        step(j, load(j, reg >> shift_state));
     }
 }
 
