@@ -54,8 +54,8 @@ extern "C" {
 #define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 3,4,5,7,9; R <= 4).
                                The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
-#define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, butterfly per thread, u32 metrics double-buffered in LDS
-                               (K = 11..15, R <= 6, any polynomials)                                                  */
+#define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32
+                               metrics double-buffered in LDS (K = 11..15, R <= 6, any polynomials)                  */
 
 typedef struct vit_hip_decoder* vit_hip_handle;
 typedef void* vit_hip_stream_t;
