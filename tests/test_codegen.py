@@ -1,0 +1,102 @@
+"""Code-generation guards (CPU only: hipcc cross-compiles gfx950 without a GPU).  The kernels' speed depends on properties
+the compiler can silently take away: register budgets that allow the intended occupancy, no scratch in the hot loops, and
+row rings that keep COUNTED s_waitcnt vmcnt(N) (a store next to the loads turns them into vmcnt(0) drains -- DESIGN.md 4.2)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "viterbidecodercpp_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+def _compile(src, defines, tmp_path):
+    out = tmp_path / "k.s"
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+           "-Rpass-analysis=kernel-resource-usage", "-o", str(out), src] + defines
+    p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    return out.read_text(), usage
+
+
+def _kernel_body(asm, symbol_regex):
+    m = re.search(r"^(" + symbol_regex + r"):", asm, re.M)
+    assert m, symbol_regex
+    return asm[m.end():asm.index(".Lfunc_end", m.end())]
+
+
+def _inner_loops(body):
+    """(start, end) line ranges of backward branches, innermost first"""
+    lines = body.split("\n")
+    labels = {m.group(1): n for n, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for n, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < n:
+            loops.append((labels[m.group(1)], n))
+    return lines, sorted(loops, key=lambda ab: ab[1] - ab[0])
+
+
+def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
+    asm, usage = _compile("reg_inst.hip", ["-DVIT_REG_ID=0"], tmp_path)
+    upd = [k for k in usage if "reg_update_kernel" in k]
+    cb = [k for k in usage if "reg_chainback_kernel" in k]
+    assert len(upd) == 2 and len(cb) == 1
+    def alloc(u):   # registers are allocated in granules of 8 (MI355X_MICROARCH.md, register files)
+        return -(-(u["VGPRs"] + u.get("AGPRs", 0)) // 8) * 8
+
+    assert usage[cb[0]]["ScratchSize"] == 0
+    for k in upd:
+        # two update waves (2048 tiles on 1024 SIMDs) + one chainback wave must fit a SIMD's 512 registers
+        assert usage[k]["ScratchSize"] == 0, (k, usage[k])
+        assert 2 * alloc(usage[k]) + alloc(usage[cb[0]]) <= 512, (k, usage[k], usage[cb[0]])
+    # the chainback ring: the innermost loop that refills rows must wait with counted vmcnt, never vmcnt(0), and hold no store
+    lines, loops = _inner_loops(_kernel_body(asm, r"_ZN3vit20reg_chainback_kernel\S*"))
+    ring = [(a, b) for a, b in loops if sum("global_load_dwordx4" in l for l in lines[a:b]) >= 16]
+    assert ring, "row-ring loop not found"
+    a, b = ring[0]
+    text = "\n".join(lines[a:b])
+    assert "global_store" not in text and "scratch_" not in text
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
+    assert waits and all(int(w) > 0 for w in waits), waits
+
+
+def test_k15_kernel_fits_one_workgroup_per_cu(tmp_path):
+    asm, usage = _compile("vit_hip.hip", [], tmp_path)
+    k15 = [k for k in usage if "lds2_update_kernelILi15ELi0" in k]
+    assert len(k15) == 1
+    u = usage[k15[0]]
+    # 1024 threads per workgroup = 4 waves per SIMD: 128 registers at most; the fast path must not spill
+    assert u["VGPRs"] + u.get("AGPRs", 0) <= 128, u
+    assert u["ScratchSize"] <= 32, u
+    body = _kernel_body(asm, r"_ZN3vit18lds2_update_kernelILi15ELi0EEEvNS_14Lds2UpdateArgsE")
+    lines, loops = _inner_loops(body)
+    main = max(loops, key=lambda ab: ab[1] - ab[0])
+    # the two fast blocks (four stages back to back between two barriers: 32 table reads, four 16-byte metric stores) must be
+    # free of scratch traffic; the rare careful path may reload a few hoisted values
+    seg, fast = [], []
+    for l in lines[main[0]:main[1]] + ["s_barrier"]:
+        if "s_barrier" in l:
+            if sum("ds_read_b64" in x for x in seg) >= 30 and sum("ds_write_b128" in x for x in seg) == 4:
+                fast.append(seg)
+            seg = []
+        else:
+            seg.append(l)
+    assert len(fast) == 2, len(fast)
+    for seg in fast:
+        assert not any("scratch_load" in x for x in seg), "the fast path reloads spilled registers"
