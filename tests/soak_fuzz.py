@@ -58,4 +58,6 @@ while time.time() < t_end:
                     assert np.array_equal(out[f], want[f]["bytes"]), ("bytes", tag)
             n += 1
     seed += 1
+    if seed % 200 == 0:
+        print(f"  ... {n} cases, seed {seed}", flush=True)
 print(f"soak ok: {n} random (code, width, config) cases, last seed {seed - 1}")
