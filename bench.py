@@ -6,12 +6,19 @@ resident in HBM.  Workload at N=1: BASELINE.json configs[1] -- Voyager K=7 R=1/2
 65536 frames x 8192 info bits.  With --gpus N the frames of every rank are independent (weak scaling: each GPU decodes its
 own 65536 frames); the only collective is the broadcast of the branch-table/config blob from rank 0 at set-up (RCCL).
 
+Launch forms:
+  python bench.py [--gpus 1]                       one rank on cuda:0
+  torchrun --nproc-per-node N bench.py --gpus N    the driver's form: RANK/LOCAL_RANK/WORLD_SIZE come from the environment
+  python bench.py --gpus N                         this process only spawns N fresh children (one rank per GPU) BEFORE
+                                                   touching the GPU, waits for them and exits with their status
+
 Prints ONE JSON line on rank 0 (see the contract in the round prompt): value = decoded info Mbit/s over all GPUs.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,7 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4
+# cycles one SIMD needs per wave64 VALU instruction in a stream of packed 16-bit / VOP3 forms at >= 2 waves per SIMD, measured
+# on the box with scripts/ubench/valu_rate.hip (profiles/r1_valu_issue_rates.txt)
+VALU_CYCLES_PER_INSTR = 4.3
 
 
 def parse():
@@ -34,58 +46,198 @@ def parse():
     ap.add_argument("--ebn0", type=float, default=3.0)
     ap.add_argument("--plan", default="auto", choices=["auto", "lds", "reg", "lds2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline's timed passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
                     help="2: double-buffered decision workspaces, chainback of step i on a second HIP stream beside the "
                          "update of step i+1; 1: both kernels back to back on one stream")
+    ap.add_argument("--synth", default="torch", choices=["hip", "torch"],
+                    help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
     return ap.parse_args()
 
 
-def cpu_baseline(code_id, code, pc, decode_type, sym_host, tx_host, L, target_seconds):
-    """The reference's own AVX2 strategy (oracle/_ref, kind "reference") on all host cores over a bounded sample of the
-    same frames; falls back to the C restatement (kind "port", scalar) where _ref was never built."""
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one rank each.  This parent never
+    touches the GPU (torch.cuda.device_count() does not initialise it on this image) and never exec()s."""
+    import torch
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if not args.share_gpu and have < n:
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (use --share-gpu only to rehearse the N>1 path)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc if rc >= 0 else 1)
+
+
+def host_cpu_topology():
+    """One logical CPU per PHYSICAL core of ONE socket, restricted to what this process may use (affinity mask and cgroup
+    CPU quota).  north_star's comparator is the single-socket AVX2 reference."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    per_pkg = {}
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        per_pkg.setdefault(pkg, {}).setdefault(core, c)     # first hardware thread of each core
+    sockets = sorted(per_pkg)
+    socket0 = sorted(per_pkg[sockets[0]].values())
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    use = socket0
+    if quota is not None and quota >= 1 and len(use) > int(quota):
+        use = use[:int(quota)]       # more runnable threads than the quota only adds throttling
+    return {"model": model, "sockets_visible": len(sockets), "physical_cores_socket0": len(socket0),
+            "logical_cpus_allowed": len(allowed), "cgroup_cpu_quota": quota, "cpus": use}
+
+
+def cpu_baseline(code_id, code, pc, decode_type, sym_dev, L, target_seconds):
+    """The reference's own AVX2 strategy (oracle/_ref, kind "reference") on the physical cores of one socket of this host,
+    over a bounded sample of the GPU batch; falls back to the C restatement (kind "port", scalar) where _ref was never
+    built.  Persistent pinned threads, barrier-to-barrier passes of >= 0.25 s, median (oracle/ref_shim.cpp: bench_one)."""
     import numpy as np
     from oracle import pyoracle
 
     pyoracle.ensure_built()
     dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[decode_type]
     ocfg = pyoracle.stock_config(dt, code.R)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    frames = sym_host.shape[0]
-    bits = frames * L
-    res = {}
-    if pyoracle.RefLib.available():
-        ref = pyoracle.RefLib()
-        simd = pyoracle.SIMD_AVX if ref.is_valid(code_id, pc.soft_bytes, pyoracle.SIMD_AVX) else pyoracle.SCALAR
-        t1, out = ref.bench(code_id, ocfg, sym_host, frames, L, simd=simd, threads=cores, reps=1)
-        reps = max(1, min(2000, int(target_seconds / max(t1, 1e-3))))
-        t, out = ref.bench(code_id, ocfg, sym_host, frames, L, simd=simd, threads=cores, reps=reps)
-        # single-thread scalar (the parity reference) on a slice, for context
-        ns = max(1, min(frames, 64))
-        ts, out_s = ref.bench(code_id, ocfg, sym_host[:ns], ns, L, simd=pyoracle.SCALAR, threads=1, reps=1)
-        res = {"value": bits / t / 1e6, "unit": "Mbit/s", "cores": cores, "kind": "reference",
-               "strategy": {pyoracle.SIMD_AVX: "ViterbiDecoder_AVX_u16/u8", pyoracle.SCALAR: "ViterbiDecoder_Scalar"}[simd],
-               "sample": f"{frames} frames x {L} bits of the GPU batch, best of {reps} passes, {cores} threads "
-                         f"(one decoder per thread, shared branch table)",
-               "scalar_1thread_Mbit_s": ns * L / ts / 1e6}
-        scalar_bytes = out_s
-    else:
+    topo = host_cpu_topology()
+    cpus = topo["cpus"]
+    T = len(cpus)
+    F = sym_dev.shape[0]
+    if not pyoracle.RefLib.available():
+        nf = min(F, max(8, 2 * T))
+        sym_host = sym_dev[:nf].cpu().numpy()
         oracle = pyoracle.Oracle()
         t0 = time.perf_counter()
-        scalar_bytes, _, _ = oracle.decode_frames(code.K, code.R, code.G, ocfg, sym_host, L, threads=cores)
+        oracle.decode_frames(code.K, code.R, code.G, ocfg, sym_host, L, threads=T)
         t = time.perf_counter() - t0
-        ns = frames
-        res = {"value": bits / t / 1e6, "unit": "Mbit/s", "cores": cores, "kind": "port",
-               "strategy": "oracle/viterbi_oracle.c (scalar restatement)",
-               "sample": f"{frames} frames x {L} bits of the GPU batch, 1 pass, {cores} threads"}
-    return res, scalar_bytes, ns
+        return {"value": nf * L / t / 1e6, "unit": "Mbit/s", "cores": T, "kind": "port",
+                "strategy": "oracle/viterbi_oracle.c (scalar restatement)",
+                "sample": f"{nf} frames x {L} bits of the GPU batch, 1 pass, {T} threads", "host": topo}
+    ref = pyoracle.RefLib()
+    simd = pyoracle.SIMD_AVX if ref.is_valid(code_id, pc.soft_bytes, pyoracle.SIMD_AVX) else pyoracle.SCALAR
+    strategy = {pyoracle.SIMD_AVX: "ViterbiDecoder_AVX_u16/u8", pyoracle.SCALAR: "ViterbiDecoder_Scalar"}
+    # one thread first: its rate sizes everything else (and is reported: the per-thread rate of the T-thread run must be
+    # within 2x of it, else the T-thread figure is measuring the host's scheduling, not decoding)
+    n1 = max(1, min(F, 64 if code.K < 11 else 2))
+    sym1 = sym_dev[:n1].cpu().numpy()
+    s1, _ = ref.bench(code_id, ocfg, sym1, n1, L, simd=simd, threads=1, passes=1, sweeps=1, cpus=cpus[:1])
+    sweeps1 = max(1, int(0.25 / max(s1[0], 1e-6)))
+    s1, _ = ref.bench(code_id, ocfg, sym1, n1, L, simd=simd, threads=1, passes=3, sweeps=sweeps1, cpus=cpus[:1])
+    rate1 = n1 * L * sweeps1 / float(np.median(s1))             # bit/s, one thread
+    # T threads: >= 256 frames per thread (K < 11), each pass >= 0.25 s
+    per_thread = 256 if code.K < 11 else 2
+    nf = max(T, min(F, per_thread * T))
+    sym_host = sym_dev[:nf].cpu().numpy()
+    est_pass = (nf / T) * L / rate1
+    sweeps = max(1, int(0.25 / est_pass + 0.999))
+    passes = max(3, min(41, int(target_seconds / (est_pass * sweeps))))
+    sT, _ = ref.bench(code_id, ocfg, sym_host, nf, L, simd=simd, threads=T, passes=passes, sweeps=sweeps, cpus=cpus)
+    med = float(np.median(sT))
+    rateT = nf * L * sweeps / med
+    # single-thread scalar (the parity reference) for context
+    ns = max(1, min(F, 16 if code.K < 11 else 1))
+    ss, _ = ref.bench(code_id, ocfg, sym_dev[:ns].cpu().numpy(), ns, L, simd=pyoracle.SCALAR, threads=1, passes=3, sweeps=1,
+                      cpus=cpus[:1])
+    res = {"value": rateT / 1e6, "unit": "Mbit/s", "cores": T, "kind": "reference", "strategy": strategy[simd],
+           "sample": f"{nf} frames x {L} bits of the GPU batch ({nf // T} frames per thread), median of {passes} passes of "
+                     f"{sweeps} sweep(s) ({med * 1e3:.0f} ms per pass, min {float(np.min(sT)) * 1e3:.0f} / max "
+                     f"{float(np.max(sT)) * 1e3:.0f}), {T} persistent threads pinned one per physical core of socket 0, "
+                     f"barrier to barrier (no thread creation inside a pass), one decoder per thread, shared branch table",
+           "per_thread_Mbit_s": rateT / T / 1e6, "simd_1thread_Mbit_s": rate1 / 1e6,
+           # the box's cgroup may grant fewer CPUs than the socket has cores: a labelled linear extrapolation to the whole
+           # socket (optimistic for the CPU: all-core clocks are lower than the clocks of a partly loaded socket)
+           "single_socket_extrapolated_Mbit_s": rateT / T * topo["physical_cores_socket0"] / 1e6,
+           "scalar_1thread_Mbit_s": ns * L / float(np.median(ss)) / 1e6, "host": {k: v for k, v in topo.items() if k != "cpus"}}
+    return res
+
+
+def reference_parity(code_id, code, pc, decode_type, dec, sym_dev, out_dev, ws, F, L, n=64):
+    """n frames of the timed batch against the reference SCALAR decoder (oracle/_ref; the C restatement where that is
+    absent): chainback bytes AND every decision word."""
+    import numpy as np
+    import torch
+    from oracle import pyoracle
+
+    dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[decode_type]
+    ocfg = pyoracle.stock_config(dt, code.R)
+    n = max(1, min(F, n if code.K < 11 else 2))
+    S = L + code.K - 1
+    # the workspace layout is tile-major: export the first frames only
+    got_dec = dec.export_decisions(n, L, workspace=ws).cpu().numpy().view(np.uint64)
+    got_bytes = out_dev[:n].cpu().numpy()
+    sym = sym_dev[:n].cpu().numpy()
+    ref = pyoracle.RefLib() if pyoracle.RefLib.available() else None
+    oracle = None if ref else pyoracle.Oracle()
+    ok_b = ok_d = True
+    for f in range(n):
+        if ref:
+            w = ref.run(code_id, ocfg, sym[f], L, simd=pyoracle.SCALAR)
+        else:
+            w = oracle.decode(code.K, code.R, code.G, ocfg, sym[f], L)
+        ok_b = ok_b and np.array_equal(got_bytes[f], w["bytes"])
+        ok_d = ok_d and np.array_equal(got_dec[f], w["decisions"][:S])
+    torch.cuda.synchronize()
+    return {"frames_checked_vs_scalar_reference": int(n), "checker": "reference (oracle/_ref)" if ref else "port (oracle/)",
+            "chainback_bytes_bit_exact": bool(ok_b), "decision_words_bit_exact": bool(ok_d), "bit_exact": bool(ok_b and ok_d)}
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)          # never returns
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} from the launcher")
+    rank = int(os.environ.get("RANK", "0"))
+
     if not os.path.exists(os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")):
         # clean checkout: compile the HIP extension first (there is no other decode path to fall back to)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -102,8 +254,6 @@ def main():
     from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, _lib,
                                        dist as vdist, get_decoding_config, pack_blob, synth)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -129,9 +279,19 @@ def main():
     blob = vdist.broadcast_blob(blob, src=0, device=coll_dev)
     plan = {"auto": _lib.PLAN_AUTO, "lds": _lib.PLAN_LDS, "reg": _lib.PLAN_REG, "lds2": _lib.PLAN_LDS2}[args.plan]
     dec = BatchDecoder(device=local_rank, blob=blob, plan=plan)
+    # proof that `world` ranks hold the same decoder: sum over ranks of a checksum of the received blob
+    blob_sum = int(np.frombuffer(blob, dtype=np.uint8).astype(np.int64).sum())
+    ranks_seen, blob_sum_all = 1, blob_sum
+    if world > 1:
+        chk = torch.tensor([1, blob_sum], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        ranks_seen, blob_sum_all = int(chk[0].item()), int(chk[1].item())
 
     # ---- synthetic frames, generated directly in HBM (not timed) ----
-    tx, sym = synth.make_frames_torch(code, pc, F, L, args.ebn0, seed=1 + rank, device=dev)
+    if args.synth == "hip":
+        tx, sym = dec.synth(F, L, args.ebn0, seed=1 + rank)
+    else:
+        tx, sym = synth.make_frames_torch(code, pc, F, L, args.ebn0, seed=1 + rank, device=dev)
     out = torch.empty((F, L // 8), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
@@ -177,11 +337,16 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank = [float(F) * L * args.steps / elapsed_local / 1e6]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        rates = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor(per_rank, dtype=torch.float64, device=coll_dev))
+        per_rank = [float(r.item()) for r in rates]
 
     upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     cb_ms = float(np.mean([(e[3] if NWS == 2 else e[1]).elapsed_time(e[2]) for e in evs]))
@@ -198,53 +363,70 @@ def main():
 
     total_bits = float(F) * L * world * args.steps
     value = total_bits / elapsed / 1e6
+    step_ms = elapsed / args.steps * 1e3
     sb = pc.soft_bytes
     upd_bytes = F * (S * code.R * sb + S * W * 8)            # symbols read + decision words written
     cb_bytes = F * (L * 8 + L // 8)                          # one decision word read per decoded bit + bytes out
     achieved = upd_bytes / (upd_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src, valu_insts = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    key = f"{code.name}|{args.decode_type}|{F}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            key = f"{code.name}|{args.decode_type}|{F}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
-            traffic = tj.get(key, {}).get("update_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get(key, {})
+            traffic = tj.get("update_kernel_hbm_bytes_per_launch")
+            valu_insts = tj.get("update_kernel_valu_insts_per_launch")
+            traffic_src = f"{tj.get('source')} (builder's rocprofv3 --pmc run of this command; not measured by this run)" if tj else None
         except Exception:
             traffic = None
 
+    state_updates = float(F) * S * code.num_states            # add-compare-select results per launch
     result = {
         "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
         "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
         "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type} "
                                f"({'u16/s16' if sb == 2 else 'u8/s8'}), {F} frames x {L} info bits per GPU, "
                                f"AWGN Eb/N0={args.ebn0} dB", "frames_per_gpu": F, "bits_per_frame": L,
                    "plan": _lib.PLAN_NAMES[dec.plan], "pipeline": f"{NWS} workspace(s), {'2 HIP streams' if NWS == 2 else '1 stream'}",
+                   "synth": args.synth,
                    "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
-        "per_gpu_Mbit_s": value / world, "Msym_s": value * code.R,
+        "per_gpu_Mbit_s": value / world, "per_rank_Mbit_s": per_rank, "Msym_s": value * code.R,
+        "ranks": {"world_size": world, "ranks_in_blob_allreduce": ranks_seen, "backend": args.backend if world > 1 else None,
+                  "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world},
         "update_ms": upd_ms, "chainback_ms": cb_ms,
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": upd_bytes,
-                     "limiter": "integer VALU issue, not HBM: the kernel's measured HBM bytes equal the algorithmic bytes "
-                                "(traffic) and its waves issue VALU back to back (DESIGN.md 4.4, profiles/*_summary.md)"},
-        "roofline_end_to_end": {"achieved": (upd_bytes + cb_bytes) / ((upd_ms + cb_ms) * 1e-3) / 1e9, "unit": "GB/s",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes,
+                     "tighter_bound": "valu (roofline_valu below): the kernel's HBM bytes equal the algorithmic bytes and its "
+                                      "waves issue packed integer VALU back to back (DESIGN.md 4.4)"},
+        # wall-clock of a whole step (the two kernels overlap on two streams when --pipeline 2, so their durations do not add)
+        "roofline_end_to_end": {"bound": "hbm", "achieved": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "bytes_per_info_bit": (upd_bytes + cb_bytes) / float(F * L)},
+        "state_updates_per_s": state_updates / (upd_ms * 1e-3),
         "ber": ber,
     }
+    if valu_insts:
+        peak_ginstr = N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INSTR       # wave64 VALU instructions per ns over the chip
+        ach = valu_insts / (upd_ms * 1e-3) / 1e9
+        result["roofline_valu"] = {
+            "bound": "valu", "kernel": "update", "achieved": ach, "peak": peak_ginstr, "unit": "G wave-instr/s",
+            "frac": ach / peak_ginstr, "valu_insts_per_launch": valu_insts,
+            "valu_insts_per_state_update_pair": valu_insts * 64.0 / (state_updates / 2.0),
+            "peak_source": f"{N_SIMD} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES_PER_INSTR} cycles per packed-16 VALU instruction "
+                           "(profiles/r1_valu_issue_rates.txt)",
+            "insts_source": traffic_src}
 
     if world == 1 and not args.no_cpu_baseline:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        nf = min(F, max(256, 16 * cores))
-        sym_host = sym[:nf].cpu().numpy()
-        tx_host = tx[:nf].cpu().numpy()
-        base, scalar_bytes, ns = cpu_baseline(args.code, code, pc, args.decode_type, sym_host, tx_host, L, args.cpu_seconds)
-        result["cpu_baseline"] = base
-        gpu_bytes = out[:ns].cpu().numpy()
-        result["parity"] = {"frames_checked_vs_scalar_reference": int(ns),
-                            "bit_exact": bool(np.array_equal(gpu_bytes, scalar_bytes))}
-        result["speedup_vs_cpu_baseline"] = value / base["value"]
+        result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
+        # parity of the last timed step's results (workspace of step warmup+steps-1)
+        ws_last = wss[(args.warmup + args.steps - 1) % NWS]
+        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, dec, sym, out, ws_last, F, L)
+        result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        if "single_socket_extrapolated_Mbit_s" in result["cpu_baseline"]:
+            result["speedup_vs_single_socket_extrapolated"] = value / result["cpu_baseline"]["single_socket_extrapolated_Mbit_s"]
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -196,9 +196,9 @@ class RefLib:
 
     def __init__(self):
         self.lib = L = C.CDLL(self.PATH)
-        L.vitref_bench.restype = C.c_double
+        L.vitref_bench.restype = C.c_int
         L.vitref_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
-                                   C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+                                   C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vitref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
@@ -261,13 +261,20 @@ class RefLib:
             raise RuntimeError(f"vitref_run rc={rc}")
         return dict(decisions=dec, metrics=met, renorm_sum=int(rs.value), error=int(err.value), bytes=out)
 
-    def bench(self, code_id, cfg: DecodeConfig, symbols, frames, L, simd=SIMD_AVX, threads=1, reps=1):
-        """seconds for the best of `reps` passes of reset+update+chainback over all frames; also returns the bytes."""
+    def bench(self, code_id, cfg: DecodeConfig, symbols, frames, L, simd=SIMD_AVX, threads=1, passes=1, sweeps=1, cpus=None):
+        """reset+update+chainback over all frames on `threads` PERSISTENT host threads (created and pinned to `cpus`
+        once, released per pass by a barrier): one untimed warm-up pass, then `passes` timed passes in each of which every
+        frame is decoded `sweeps` times.  returns (seconds per pass [passes], bytes [frames][L/8])."""
         symbols = np.ascontiguousarray(symbols, dtype=cfg.soft_dtype)
         out = np.zeros((frames, (L + 7) // 8), dtype=np.uint8)
         cfg4 = np.asarray(cfg.cfg4, dtype=np.uint32)
-        sec = self.lib.vitref_bench(code_id, cfg.soft_bytes, simd, cfg.high, cfg.low, _ptr(cfg4), _ptr(symbols), frames, L,
-                                    threads, reps, _ptr(out))
-        if sec < 0:
-            raise RuntimeError(f"vitref_bench rc={sec}")
-        return sec, out
+        secs = np.zeros(max(1, passes), dtype=np.float64)
+        cpu_arr = None
+        if cpus is not None:
+            assert len(cpus) >= threads
+            cpu_arr = np.asarray(list(cpus)[:threads], dtype=np.int32)
+        rc = self.lib.vitref_bench(code_id, cfg.soft_bytes, simd, cfg.high, cfg.low, _ptr(cfg4), _ptr(symbols), frames, L,
+                                   threads, passes, sweeps, _ptr(cpu_arr), _ptr(out), _ptr(secs))
+        if rc != 0:
+            raise RuntimeError(f"vitref_bench rc={rc}")
+        return secs, out

@@ -17,6 +17,8 @@
 #include <stddef.h>
 #include <string.h>
 #include <chrono>
+#include <pthread.h>
+#include <sched.h>
 #include <thread>
 #include <vector>
 #include <memory>
@@ -51,9 +53,10 @@ struct BenchArgs {
     const uint32_t* cfg;
     const void* symbols;
     size_t frames, L;
-    int threads, reps;
+    int threads, passes, sweeps;
+    const int* cpus;         // [threads] logical CPU each worker is pinned to, or null (unpinned)
     uint8_t* bytes_out;
-    double seconds;
+    double* pass_seconds;    // [passes]
 };
 
 template <typename error_t>
@@ -95,6 +98,12 @@ int run_one(ViterbiDecoder_Core<K,R,error_t,soft_t>& dec, const RunArgs& a) {
     return 0;
 }
 
+// Timing protocol of bench.py's cpu_baseline: the T workers are created ONCE, pinned (one per physical core of one
+// socket, chosen by the caller) and parked on a barrier; a pass is the interval between the release of the start barrier
+// and the arrival of the last worker at the end barrier, during which every worker decodes its own contiguous share of the
+// frames `sweeps` times (reset -> update -> chainback per frame, one decoder per thread, one shared branch table:
+// examples/run_benchmark.cpp:193-197, :268-281).  Pass 0 is an untimed warm-up.  No thread is created or joined inside
+// a timed pass.
 template <class decoder_t, size_t K, size_t R, typename error_t, typename soft_t>
 void bench_one(const ViterbiBranchTable<K,R,soft_t>& table, const ViterbiDecoder_Config<error_t>& cfg, BenchArgs& a) {
     using Core = ViterbiDecoder_Core<K,R,error_t,soft_t>;
@@ -102,36 +111,46 @@ void bench_one(const ViterbiBranchTable<K,R,soft_t>& table, const ViterbiDecoder
     const size_t frame_syms = S*R;
     const size_t out_bytes = (a.L + 7)/8;
     const int T = std::max(1, a.threads);
-    // one decoder per thread, one shared branch table (examples/run_benchmark.cpp:193-197)
+    const int passes = std::max(1, a.passes), sweeps = std::max(1, a.sweeps);
     std::vector<std::unique_ptr<Core>> cores;
     for (int t = 0; t < T; t++) {
         cores.emplace_back(new Core(table, cfg));
         cores.back()->set_traceback_length(a.L);
     }
-    auto body = [&](int t) {
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, unsigned(T) + 1u);
+    auto worker = [&](int t) {
+        if (a.cpus) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(a.cpus[t], &set);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        }
         Core& dec = *cores[t];
         const soft_t* sym = reinterpret_cast<const soft_t*>(a.symbols);
         const size_t f0 = a.frames*size_t(t)/size_t(T), f1 = a.frames*size_t(t+1)/size_t(T);
-        for (size_t f = f0; f < f1; f++) {
-            dec.reset();
-            (void)decoder_t::template update<uint64_t>(dec, sym + f*frame_syms, frame_syms);
-            dec.chainback(a.bytes_out + f*out_bytes, a.L);
+        for (int p = 0; p <= passes; p++) {
+            pthread_barrier_wait(&bar);
+            for (int s = 0; s < sweeps; s++)
+                for (size_t f = f0; f < f1; f++) {
+                    dec.reset();
+                    (void)decoder_t::template update<uint64_t>(dec, sym + f*frame_syms, frame_syms);
+                    dec.chainback(a.bytes_out + f*out_bytes, a.L);
+                }
+            pthread_barrier_wait(&bar);
         }
     };
-    double best = 1e30;
-    for (int r = 0; r < std::max(1, a.reps); r++) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    for (int p = 0; p <= passes; p++) {
+        pthread_barrier_wait(&bar);
         const auto t0 = std::chrono::steady_clock::now();
-        if (T == 1) {
-            body(0);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < T; t++) th.emplace_back(body, t);
-            for (auto& x: th) x.join();
-        }
+        pthread_barrier_wait(&bar);
         const auto t1 = std::chrono::steady_clock::now();
-        best = std::min(best, std::chrono::duration<double>(t1 - t0).count());
+        if (p > 0) a.pass_seconds[p - 1] = std::chrono::duration<double>(t1 - t0).count();
     }
-    a.seconds = best;
+    for (auto& x: th) x.join();
+    pthread_barrier_destroy(&bar);
 }
 
 enum Op { OP_RUN, OP_BENCH, OP_VALID, OP_TABLE };
@@ -294,14 +313,16 @@ int vitref_encode(int code_id, int which, const uint8_t* bytes, size_t n_bytes, 
     return ok;
 }
 
-/* times `reps` passes of reset()+update()+chainback() over all frames on `threads` host threads; returns the best
- * pass in seconds (<0 on error).  symbols: [frames][L+K-1][R] soft_t. */
-double vitref_bench(int code_id, int bytes, int simd, int high, int low, const uint32_t* cfg,
-                    const void* symbols, size_t frames, size_t L, int threads, int reps, uint8_t* bytes_out) {
-    BenchArgs ba{simd, high, low, cfg, symbols, frames, L, threads, reps, bytes_out, -1.0};
+/* cpu_baseline timing (see bench_one): `passes` timed passes (after one warm-up pass) over all frames on `threads` persistent
+ * host threads, each frame decoded `sweeps` times per pass; pass_seconds[passes] receives the wall time of every pass.
+ * cpus: [threads] logical CPU per worker or NULL.  symbols: [frames][L+K-1][R] soft_t.  returns 0, <0 on error. */
+int vitref_bench(int code_id, int bytes, int simd, int high, int low, const uint32_t* cfg,
+                 const void* symbols, size_t frames, size_t L, int threads, int passes, int sweeps, const int* cpus,
+                 uint8_t* bytes_out, double* pass_seconds) {
+    BenchArgs ba{simd, high, low, cfg, symbols, frames, L, threads, passes, sweeps, cpus, bytes_out, pass_seconds};
     Call c{OP_BENCH, bytes, nullptr, &ba, nullptr, -1};
     dispatch_code(code_id, c);
-    return c.result == 0 ? ba.seconds : double(c.result);
+    return c.result;
 }
 
 } // extern "C"

@@ -1,0 +1,72 @@
+"""bench.py as the driver runs it: one JSON line, the --gpus N launcher really starts N ranks, the reporting fields add up."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=ROOT)
+    return p
+
+
+def _json_line(p):
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_launcher_refuses_more_ranks_than_gpus_without_share_gpu():
+    # runs without a GPU too: the parent must fail loudly before any rank is started
+    p = _run("--gpus", "64")
+    assert p.returncode != 0 and "--gpus 64" in (p.stderr + p.stdout)
+
+
+def test_gpus_flag_must_agree_with_the_launcher_environment():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=env, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_gpus_2_spawns_two_ranks_on_one_card():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns two fresh rank processes (here both on cuda:0, gloo for
+    the collectives -- the RCCL/xGMI form needs two cards) and rank 0 reports the aggregate."""
+    r = _json_line(_run("--gpus", "2", "--share-gpu", "--backend", "gloo", "--frames", "4096", "--bits", "1024",
+                        "--steps", "3", "--warmup", "1"))
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["ranks"]["world_size"] == 2 and r["ranks"]["ranks_in_blob_allreduce"] == 2
+    assert r["ranks"]["blob_checksum_identical_on_all_ranks"] is True
+    assert len(r["per_rank_Mbit_s"]) == 2 and all(v > 0 for v in r["per_rank_Mbit_s"])
+    assert "cpu_baseline" not in r            # rank 0 at N=1 only
+    assert 0 <= r["ber"] < 1e-2
+
+
+@pytest.mark.gpu
+def test_single_rank_line_is_self_consistent():
+    r = _json_line(_run("--frames", "8192", "--bits", "2048", "--steps", "4", "--warmup", "1", "--cpu-seconds", "2"))
+    assert r["n_gpus"] == 1 and r["unit"] == "Mbit/s" and r["dtype"] == "u16" and r["vs_baseline"] is None
+    bits = 8192 * 2048 * 4
+    assert abs(r["value"] - bits / (r["ms_per_step"] * 4e-3) / 1e6) / r["value"] < 1e-6
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["frac"] < 1
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (r["update_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    e2e = r["roofline_end_to_end"]
+    assert abs(e2e["achieved"] - e2e["bytes_per_info_bit"] * 8192 * 2048 / (r["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * e2e["achieved"]
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    if cb["kind"] == "reference":
+        # threads really decode in parallel: the per-thread rate is within 2x of one thread alone
+        assert cb["per_thread_Mbit_s"] * 2 > cb["simd_1thread_Mbit_s"]
+    par = r["parity"]
+    assert par["bit_exact"] and par["decision_words_bit_exact"] and par["chainback_bytes_bit_exact"]

@@ -335,11 +335,13 @@ class BatchDecoder:
                                                         C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
-    def export_decisions(self, frames: int, L: int, n_steps: int = None):
-        """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words)."""
+    def export_decisions(self, frames: int, L: int, n_steps: int = None, workspace=None):
+        """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words).  Every
+        plan's workspace is frame-major in units that do not depend on the batch size, so the first `frames` frames of a
+        larger batch's workspace can be exported on their own."""
         t = self.torch
         n_steps = (L + self.K - 1) if n_steps is None else n_steps
-        ws = self._workspace(frames, L)
+        ws = self._workspace(frames, L, workspace)
         dec = t.empty((frames, n_steps, self.W), dtype=t.int64, device=self.device)
         _lib.check(_lib.load().vit_hip_export_decisions(self._handle._h, C.c_void_p(ws.data_ptr()), frames, n_steps, L,
                                                         C.c_void_p(dec.data_ptr()), self._stream()))
