@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
                     help="2: double-buffered decision workspaces, chainback of step i on a second HIP stream beside the "
                          "update of step i+1; 1: both kernels back to back on one stream")
-    ap.add_argument("--synth", default="torch", choices=["hip", "torch"],
+    ap.add_argument("--synth", default="hip", choices=["hip", "torch"],
                     help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
     return ap.parse_args()
 
@@ -289,7 +289,7 @@ def main():
 
     # ---- synthetic frames, generated directly in HBM (not timed) ----
     if args.synth == "hip":
-        tx, sym = dec.synth(F, L, args.ebn0, seed=1 + rank)
+        tx, sym = dec.synth(F, L, args.ebn0, seed=1, first_frame=rank * F)    # rank r owns frames [r*F, (r+1)*F) of one global batch
     else:
         tx, sym = synth.make_frames_torch(code, pc, F, L, args.ebn0, seed=1 + rank, device=dev)
     out = torch.empty((F, L // 8), dtype=torch.uint8, device=dev)

@@ -20,6 +20,16 @@
  *   vit_hip_depuncture_batch  decode_punctured_symbols()          examples/helpers/puncture_code_helpers.h:17-55 (the
  *                             re-insertion of punctured symbols as the erasure value 0, for a whole batch; the update
  *                             itself then runs through vit_hip_update_batch instead of one update() per R symbols)
+ *   vit_hip_reset_batch       reset(starting_state)               viterbi_decoder_core.h:202-211, for a batch of decoders
+ *   vit_hip_update_batch_resume  update() called again on a decoder that already holds state: the cursor
+ *                             m_current_decoded_bit and the metrics carry over
+ *                                                                 viterbi_decoder_scalar.h:29-55 (:37-54 the cursor)
+ *   vit_hip_broadcast_table   "Branch table can be shared between multiple decoders"   README.md:14,
+ *                             viterbi_branch_table.h:17-18, one decoder per worker examples/run_benchmark.cpp:193-197:
+ *                             here the workers are GPUs and the table travels once over RCCL/xGMI
+ *   vit_hip_synth_batch       the BER harness's frame generator   examples/run_snr_ber.cpp:311-359,
+ *                             examples/helpers/test_helpers.h:17-64, convolutional_encoder_shift_register.h:42-62
+ *   vit_hip_count_bit_errors  get_total_bit_errors()              examples/helpers/test_helpers.h:95-104
  *
  * Semantics are those of the reference SCALAR strategy (strict '>' decision, wrapping error_t arithmetic,
  * renormalise only when new_metric[0] >= threshold): SURVEY.md section 8(a').  All results are bit-exact.
@@ -131,6 +141,50 @@ int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t f
  *   d_symbols_out   [frames][symbols_per_frame] soft_t */
 int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t punctured_per_frame,
                              const int32_t* d_source_index, size_t symbols_per_frame, size_t frames, void* d_symbols_out,
+                             vit_hip_stream_t stream);
+
+/* ---- batched streaming: a batch of decoders fed in chunks, state resident on the device ------------------------- */
+
+/* reset(start_state) for every frame: d_metrics [frames][N] error_t <- initial_non_start_error, initial_start_error at the
+ * start state (d_start_state [frames] uint32 or NULL => 0). */
+int vit_hip_reset_batch(vit_hip_handle h, size_t frames, const uint32_t* d_start_state, void* d_metrics,
+                        vit_hip_stream_t stream);
+
+/* update() on decoders that already hold state: NO reset.  Every frame's cursor stands at trellis step `first_step`
+ * (= m_current_decoded_bit) and its metrics are in d_metrics_inout [frames][N] error_t; the call consumes n_steps more
+ * steps (first_step + n_steps <= L + K-1), writes decision rows [first_step, first_step + n_steps) of the workspace and
+ * leaves the new metrics in d_metrics_inout.  A sequence of calls over consecutive step ranges is bit-identical to one
+ * vit_hip_update_batch over the whole range (decision rows, metrics, and the renormalisation sums added up).
+ *   d_symbols            frame f's chunk starts at d_symbols + f * symbol_frame_stride (in soft_t elements) and holds
+ *                        [n_steps][R]; symbol_frame_stride = 0 means n_steps * R (chunks packed back to back)
+ *   d_renorm_sum         [frames] uint64 or NULL: update()'s return value for THIS call (not accumulated) */
+int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t symbol_frame_stride, size_t frames,
+                                size_t first_step, size_t n_steps, size_t L, void* d_workspace, size_t workspace_bytes,
+                                void* d_metrics_inout, uint64_t* d_renorm_sum, vit_hip_stream_t stream);
+
+/* ---- multi-GPU set-up for C/C++ hosts ----------------------------------------------------------------------------------- */
+
+/* Broadcast the shared branch table + config from rank `root` to every rank of an RCCL communicator (ncclComm_t passed as
+ * void*), over xGMI: the one collective of the multi-GPU path (frames shard with no data-path exchange).  On `root`
+ * branch_table / config are inputs, on the other ranks they are outputs ([R][H] soft_t and 4 x error_t); every rank passes
+ * the same K, R and widths (template parameters in the reference).  Collective and synchronous on `stream`.  librccl.so is
+ * dlopen()ed on first use: the library carries no link-time dependency on RCCL. */
+int vit_hip_broadcast_table(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
+                            void* branch_table, void* config, int device, vit_hip_stream_t stream);
+
+/* ---- synthetic frames and error counting on the device (test / measurement harness) ----------------------------------- */
+
+/* The reference BER harness's generator for a whole batch, in one kernel: random info bytes -> convolutional encoder
+ * (MSB-first bits, K-1 zero tail bits) -> +-1 BPSK + N(0, sigma^2) -> round / clamp to [low, high]
+ * (sigma^2 = 10^(-(ebn0_db - 10 log10 R + 3)/10), scale (high-low)/2 / sqrt(1 + sigma^2): run_snr_ber.cpp:319-359).
+ * Every value is a pure function of (seed, first_frame + f, position) through Philox4x32-10: splitting a batch over calls
+ * or ranks does not change it.  noise_free != 0: symbols are exactly high / low (ebn0_db ignored).
+ *   d_tx_bytes [frames][L/8] or NULL (L % 8 == 0) ; d_symbols [frames][L+K-1][R] soft_t */
+int vit_hip_synth_batch(vit_hip_handle h, size_t frames, size_t L, uint64_t seed, uint64_t first_frame, float ebn0_db,
+                        int noise_free, uint8_t* d_tx_bytes, void* d_symbols, vit_hip_stream_t stream);
+
+/* *d_count (uint64, device) += number of differing bits between two device byte arrays. */
+int vit_hip_count_bit_errors(vit_hip_handle h, const uint8_t* d_a, const uint8_t* d_b, size_t n_bytes, uint64_t* d_count,
                              vit_hip_stream_t stream);
 
 /* ---- host-pointer compatibility route (one decoder object, streaming) ------------------------------------------ */

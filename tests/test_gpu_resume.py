@@ -1,0 +1,111 @@
+"""Batched streaming: a batch of decoders fed in chunks through vit_hip_update_batch_resume (the reference's update() is
+incrementally callable with a cursor: viterbi_decoder_scalar.h:29-55, puncture_code_helpers.h:51).  Any split of the steps
+must give the same decision rows, metrics, renormalisation sums and bytes as one call -- and as the oracle."""
+import numpy as np
+import pytest
+
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, _lib, synth
+from tests.helpers import gpu_metrics_to_u32, make_table_config, oracle_frames
+
+pytestmark = pytest.mark.gpu
+
+K11 = Code("K11 R=1/2", 11, 2, (0o3345, 0o3613))
+K6 = Code("K6 R=1/2", 6, 2, (0o65, 0o57))
+
+CASES = [
+    (COMMON_CODES[2], "SOFT16", _lib.PLAN_REG, 67, 336),      # K7: 24-step blocks, 4-step decision rows
+    (COMMON_CODES[2], "HARD8", _lib.PLAN_REG, 33, 200),
+    (COMMON_CODES[3], "SOFT8", _lib.PLAN_REG, 40, 152),       # K7 R3: odd symbol strides
+    (COMMON_CODES[4], "SOFT16", _lib.PLAN_REG, 35, 144),      # K7 R4: 8-step LDS ring
+    (COMMON_CODES[5], "SOFT16", _lib.PLAN_REG, 37, 120),      # K9
+    (COMMON_CODES[6], "SOFT16", _lib.PLAN_REG, 20, 96),       # K9 R4
+    (COMMON_CODES[0], "SOFT16", _lib.PLAN_REG, 130, 104),     # K3
+    (COMMON_CODES[1], "SOFT8", _lib.PLAN_REG, 130, 104),      # K5
+    (K11, "SOFT16", _lib.PLAN_LDS2, 5, 72),
+    (COMMON_CODES[7], "SOFT16", _lib.PLAN_LDS2, 3, 40),       # K15
+    (K6, "SOFT16", _lib.PLAN_LDS, 4, 88),
+    (COMMON_CODES[2], "SOFT16", _lib.PLAN_LDS, 3, 88),
+]
+
+
+def _splits(S, rng, style):
+    if style == "halves":
+        return [S // 2, S - S // 2]
+    if style == "ones_then_rest":
+        return [1, 1, 1, 2, 3, S - 8]
+    cuts, left = [], S
+    while left > 0:
+        n = int(rng.integers(1, min(left, 61) + 1))
+        cuts.append(n)
+        left -= n
+    return cuts
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("style", ["halves", "ones_then_rest", "random"])
+def test_chunked_update_equals_one_call_and_the_oracle(oracle, case, style):
+    import torch
+
+    code, decode_type, plan, F, L = CASES[case]
+    pc, table, config = make_table_config(code, decode_type)
+    S = L + code.K - 1
+    rng = np.random.default_rng(1000 * case + len(style))
+    ebn0 = 1.0 if code.K < 15 else -4.0
+    _, sym = synth.make_frames_numpy(code, pc, F, L, ebn0, seed=case)
+    # small thresholds make renormalisation frequent so that chunk boundaries meet it in every position
+    start = rng.integers(0, code.num_states, F).astype(np.int32)
+    end = rng.integers(0, code.num_states, F).astype(np.int32)
+    d_sym = torch.from_numpy(sym).cuda()
+
+    dec = BatchDecoder(table, config, plan=plan)
+    met1, rs1 = dec.update(d_sym, L, start_state=start)
+    dec1 = dec.export_decisions(F, L).clone()
+    out1 = dec.chainback(F, L, end_state=end).clone()
+
+    dec2 = BatchDecoder(table, config, plan=plan)
+    ws = dec2.new_workspace(F, L)
+    ws.fill_(0xA5)                                   # stale contents must not leak into the rows
+    met2 = dec2.reset_batch(F, start_state=start)
+    rs2 = torch.zeros(F, dtype=torch.int64, device="cuda")
+    t = 0
+    for i, n in enumerate(_splits(S, rng, style)):
+        if i % 2 == 0:      # packed chunk
+            chunk = d_sym[:, t:t + n].contiguous()
+            rs2 += dec2.update_resume(chunk, L, t, met2, workspace=ws)
+        else:               # a view into the whole batch: frame stride S*R
+            view = d_sym.reshape(-1)[t * code.R:]
+            rs2 += dec2.update_resume(view, L, t, met2, n_steps=n, symbol_frame_stride=S * code.R, workspace=ws)
+        t += n
+    assert t == S
+    assert torch.equal(met1, met2), "metrics differ between one call and the chunked calls"
+    assert torch.equal(rs1, rs2), "renormalisation sums differ"
+    assert torch.equal(dec2.export_decisions(F, L, workspace=ws), dec1), "decision rows differ"
+    assert torch.equal(dec2.chainback(F, L, end_state=end, workspace=ws), out1)
+    # and both are the reference's answer
+    want = oracle_frames(oracle, code, decode_type, sym, L, S, start, end)
+    assert np.array_equal(dec1.cpu().numpy().view(np.uint64), want["decisions"])
+    assert np.array_equal(gpu_metrics_to_u32(met2, pc.error_bytes), want["metrics"])
+    assert np.array_equal(rs2.cpu().numpy().astype(np.uint64), want["renorm_sum"])
+    assert np.array_equal(out1.cpu().numpy(), want["bytes"])
+
+
+def test_resume_argument_checks():
+    import ctypes as C
+    import torch
+
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    F, L = 4, 64
+    S = L + code.K - 1
+    sym = torch.zeros((F, 10, code.R), dtype=torch.int16, device="cuda")
+    met = dec.reset_batch(F)
+    with pytest.raises(_lib.VitHipError):           # runs past the traceback length
+        dec.update_resume(sym, L, S - 5, met)
+    with pytest.raises(_lib.VitHipError):           # stride shorter than a chunk
+        dec.update_resume(sym, L, 0, met, symbol_frame_stride=3)
+    lib = _lib.load()
+    ws = dec.new_workspace(F, L)
+    rc = lib.vit_hip_update_batch_resume(dec._handle._h, C.c_void_p(sym.data_ptr()), 0, F, 0, 10, L, C.c_void_p(ws.data_ptr()),
+                                         ws.numel(), None, None, None)
+    assert rc == _lib.ERR_INVALID_ARG

@@ -71,7 +71,9 @@ struct Lds2UpdateArgs {
     uint64_t* renorm_sum;            // [F] or null
     const u32* start_state;          // [F] or null
     const uint16_t* pattern;         // [H] bit i = (branch_table[i][j] == high)
-    u32 frames, n_steps;
+    const void* metrics_in;          // [F][N] error_t: resume from these metrics (no reset); null => reset(start_state)
+    u32 frames;
+    u32 t_begin, t_end;              // trellis steps [t_begin, t_end) of every frame; the symbol chunk starts at step t_begin
     int32_t R;
     DevConfig cfg;
 };
@@ -162,8 +164,21 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         });
     });
 
-    // ---- reset (viterbi_decoder_core.h:202-211) ----
-    {
+    // ---- reset (viterbi_decoder_core.h:202-211), or resume from the metrics an earlier call left ----
+    if (a.metrics_in) {
+        for (int s = tid; s < N; s += T) {
+            u32 lo, hi;
+            if (SHIFT) {
+                lo = (u32)((const uint8_t*)a.metrics_in)[(size_t)fA * N + s] << 8;
+                hi = (u32)((const uint8_t*)a.metrics_in)[(size_t)fB * N + s] << 8;
+            } else {
+                lo = ((const uint16_t*)a.metrics_in)[(size_t)fA * N + s];
+                hi = ((const uint16_t*)a.metrics_in)[(size_t)fB * N + s];
+            }
+            met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
+        }
+        if (tid < 16) flag[tid] = 0;
+    } else {
         const u32 sA = a.start_state ? (a.start_state[fA] & (u32)(N - 1)) : 0u;
         const u32 sB = a.start_state ? (a.start_state[fB] & (u32)(N - 1)) : 0u;
         for (int s = tid; s < N; s += T) {
@@ -177,8 +192,9 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     // ---- branch-metric table builder: lane p makes entry p of the table of one step ----
     const uint8_t* symA = a.symbols + (size_t)fA * a.sym_frame_stride_bytes;
     const uint8_t* symB = a.symbols + (size_t)fB * a.sym_frame_stride_bytes;
-    auto load_syms = [&](u32 step, u32 (&y)[6]) __attribute__((always_inline)) {
-        // packed (frame A | frame B << 16) symbols of `step` in the device's 16-bit domain
+    auto load_syms = [&](u32 abs_step, u32 (&y)[6]) __attribute__((always_inline)) {
+        // packed (frame A | frame B << 16) symbols of trellis step `abs_step` in the device's 16-bit domain
+        const u32 step = abs_step - a.t_begin;      // the chunk starts at step t_begin
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
@@ -217,19 +233,20 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.n_steps) load_syms(t0 + (u32)c, ysym[i]);
+            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) load_syms(t0 + (u32)c, ysym[i]);
         }
     };
     auto tables_build = [&](u32 t0, int buf) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.n_steps) build_table(etab + (buf * BLK + c) * 64, ysym[i]);
+            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) build_table(etab + (buf * BLK + c) * 64, ysym[i]);
         }
     };
-    tables_load(0);
-    tables_build(0, 0);
-    tables_load(BLK);
+    const u32 tb0 = a.t_begin & ~(u32)(BLK - 1);   // the block that holds step t_begin (0 for a fresh decode)
+    tables_load(tb0);
+    tables_build(tb0, 0);
+    tables_load(tb0 + BLK);
     __syncthreads();
 
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
@@ -299,17 +316,28 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     };
     // the careful version of a block: `nst` stages (1..4) with the threshold test and the reduction after EVERY stage; used
     // when thread 0 saw state 0 cross the threshold inside a block, and for the last partial block of a frame
-    auto slow_block = [&](u32 t0, int buf, int nst) __attribute__((always_inline)) {
+    auto slow_block = [&](u32 t0, int buf, int c_first, int nst, bool build_next) __attribute__((always_inline)) {
         const u32* src = met + buf * N;
         u32* dst = met + (buf ^ 1) * N;
+        if (build_next) {                      // entry block of a resumed call: nobody has built the next block's tables yet
+            tables_build(t0 + BLK, buf ^ 1);
+            tables_load(t0 + 2 * BLK);
+        }
         // an opaque copy of the thread index: the 3 x 16 scatter addresses of the partial-block write-back below are loop
         // invariant, and hoisted out of the main loop they cost the FAST path its registers (spills) for a once-per-frame use
         u32 tid_o = (u32)tid;
         asm volatile("" : "+v"(tid_o));
-        load_metrics(src);
+        if (c_first == 0) {
+            load_metrics(src);
+        } else {                               // mid-block entry: the registers as stage c_first - 1 would have left them
+            l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
+                constexpr u32 r = decltype(rc)::value;
+                m[r] = src[lds2_sw(lds2_state_of(c_first - 1, r, tid_o, SBITS), (u32)N)];
+            });
+        }
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
-            if (C < nst) {
+            if (C >= c_first && C < nst) {
                 stage(cc, (u32)(buf * BLK * 512), ws_pair + (size_t)t0 * T);
                 // state 0 is register 0 of thread 0 after every stage
                 if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
@@ -362,15 +390,18 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         return false;
     };
 
-    u32 t0 = 0;
-    int cur = 0;                              // metric / table buffer that holds the state of step t0
-    while (t0 < a.n_steps) {
-        const u32 left = a.n_steps - t0;
+    u32 t0 = tb0;
+    int cur = 0;                              // metric / table buffer that holds the state of block t0
+    while (t0 < a.t_end) {
+        const u32 left = a.t_end - t0;
         const int nst = left < (u32)BLK ? (int)left : BLK;
-        bool slow = nst < BLK;                // last, partial block: its tables were built by the block (or prologue) before
+        const int c_first = t0 < a.t_begin ? (int)(a.t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
+        // partial blocks (the entry block of a resumed call, the last block of a frame) take the careful routine; the tables
+        // of the last block were built by the block (or prologue) before it
+        bool slow = nst < BLK || c_first > 0;
         if (!slow) slow = cur == 0 ? fast_block(std::integral_constant<int, 0>{}, t0) : fast_block(std::integral_constant<int, 1>{}, t0);
-        if (slow) slow_block(t0, cur, nst);
-        t0 += (u32)nst;
+        if (slow) slow_block(t0, cur, c_first, nst, c_first > 0);
+        t0 += (u32)BLK;
         cur ^= 1;
     }
 
@@ -520,20 +551,22 @@ int lds2_launch_update_k(int K, const Lds2UpdateArgs& a, unsigned pairs, hipStre
 }
 
 inline int lds2_update(int K, int R, const DevConfig& cfg, int shift, const uint16_t* d_pattern, const void* d_symbols,
-                       size_t frames, size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm,
-                       const uint32_t* d_start, hipStream_t st) {
+                       size_t sym_stride, size_t frames, size_t first_step, size_t n_steps, size_t L, void* d_ws,
+                       const void* d_metrics_in, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start, hipStream_t st) {
     if (frames == 0 || n_steps == 0) return 0;
     Lds2UpdateArgs a{};
     a.symbols = (const uint8_t*)d_symbols;
-    a.sym_frame_stride_bytes = n_steps * (size_t)R * (shift ? 1 : 2);
+    a.sym_frame_stride_bytes = sym_stride * (shift ? 1 : 2);
     a.ws = (u32*)d_ws;
     a.ws_pair_stride = (L + (size_t)K - 1) * lds2_threads(K);
     a.metrics_out = d_metrics;
     a.renorm_sum = d_renorm;
     a.start_state = d_start;
     a.pattern = d_pattern;
+    a.metrics_in = d_metrics_in;
     a.frames = (u32)frames;
-    a.n_steps = (u32)n_steps;
+    a.t_begin = (u32)first_step;
+    a.t_end = (u32)(first_step + n_steps);
     a.R = R;
     a.cfg = cfg;
     const unsigned pairs = (unsigned)((frames + 1) / 2);

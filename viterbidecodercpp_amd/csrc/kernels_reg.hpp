@@ -169,7 +169,9 @@ struct RegUpdateArgs {
     void* metrics_out;      // [F][N] error_t or null
     uint64_t* renorm_sum;   // [F] or null
     const u32* start_state; // [F] or null
-    u32 frames, n_steps;
+    const void* metrics_in; // [F][N] error_t: resume from these metrics (no reset); null => reset(start_state)
+    u32 frames;
+    u32 t_begin, t_end;     // trellis steps [t_begin, t_end) of every frame; the symbol chunk starts at step t_begin
     DevConfig cfg;
 };
 
@@ -193,7 +195,31 @@ VIT_DEV uint4 load_chunk(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 mis, bool fi
     return r;
 }
 
-template <class SP, int SHIFT>
+// load_chunk for the entry block of a RESUMED call, whose first bytes may lie below the frame's chunk (steps before
+// t_begin): an offset that wrapped below zero makes the hardware range check fail for the WHOLE access, including the valid
+// dwords above zero, so every dword is fetched on its own and the ones below zero are skipped (per-tile offsets stay below
+// 2^31: reg_update())
+VIT_DEV uint4 load_chunk_entry(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 mis, bool fix) {
+    u32 w[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const u32 o = voff + 4u * (u32)d;
+        w[d] = ((int)o >= 0 && (d < 4 || fix)) ? (u32)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o, 0, 0) : 0u;
+    }
+    uint4 r = make_uint4(w[0], w[1], w[2], w[3]);
+    if (fix) {
+        r.x = __builtin_amdgcn_alignbyte(w[1], w[0], mis);
+        r.y = __builtin_amdgcn_alignbyte(w[2], w[1], mis);
+        r.z = __builtin_amdgcn_alignbyte(w[3], w[2], mis);
+        r.w = __builtin_amdgcn_alignbyte(w[4], w[3], mis);
+    }
+    return r;
+}
+
+// RESUME = false: reset + update from step 0 (the throughput kernel; every t_begin / metrics_in branch below folds away).
+// RESUME = true : the same steps for decoders that already hold state (vit_hip_update_batch_resume): metrics come from
+//                 metrics_in, the first unrolled block is entered in the middle.
+template <class SP, int SHIFT, bool RESUME = false>
 VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int SB = SP::SB, R = SP::R, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS, T = SP::T;
     constexpr int SBY = SHIFT ? 1 : 2;   // sizeof(soft_t)
@@ -227,6 +253,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // this kernel is VALU-issue bound; the chainback of the previous batch may be co-resident on a second stream: let
     // these waves win the issue arbitration, the (latency/HBM-bound) bit chase fills the gaps (+4 % on the overlapped step)
     __builtin_amdgcn_s_setprio(2);
+    const u32 T_BEGIN = RESUME ? a.t_begin : 0u;
     constexpr int PAIRS = SP::PAIRS, TILE = SP::TILE;
     const int lane = threadIdx.x & 63;
     const u32 g = lane & (PAIRS - 1), q = SP::LANE_BITS ? lane >> 4 : 0;
@@ -243,9 +270,12 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // be dropped (it cannot straddle an allocation granule)
     const size_t remain = (a.sym_total_bytes - tile_off + bmis + 3) & ~(size_t)3;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.symbols + tile_off - bmis), 0, remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain, 0x00020000);
-    const u32 rawA = (fA - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis;
-    const u32 rawB = (fB - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis;
+        (void*)(a.symbols + tile_off - bmis), 0, remain > 0xFFFF0000ull ? 0xFFFF0000u : (u32)remain, 0x00020000);
+    // byte offset of ABSOLUTE step 0 (mod 2^32): the chunk holds steps t_begin.. ; the look-ahead of a resumed call may
+    // touch steps below t_begin -- those offsets land in the neighbouring frame's chunk or wrap beyond num_records (reads 0),
+    // and nothing computed from them is used
+    const u32 rawA = (fA - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis - T_BEGIN * (u32)BPS;
+    const u32 rawB = (fB - (u32)tile * TILE) * (u32)a.sym_frame_stride_bytes + bmis - T_BEGIN * (u32)BPS;
     const u32 offA = rawA & ~3u, offB = rawB & ~3u, misA = rawA & 3u, misB = rawB & 3u;
     const bool fix = __builtin_amdgcn_ballot_w64((misA | misB) != 0) != 0;   // wave-uniform
 
@@ -297,9 +327,26 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     const u32 gvA = (rawA + BPS * q) & ~3u, gsA = (rawA + BPS * q) & 3u;
     const u32 gvB = (rawB + BPS * q) & ~3u, gsB = (rawB + BPS * q) & 3u;
 
-    // ---- reset (viterbi_decoder_core.h:202-211): phase 0, slot == state ----
+    // ---- reset (viterbi_decoder_core.h:202-211): phase 0, slot == state; or resume: slot x holds state rotl^ph(x) ----
     u32 m[NREG];
-    {
+    if (RESUME) {
+        const int ph = (int)(T_BEGIN % SB);
+        constexpr size_t N = (size_t)1 << SB;
+        static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
+            constexpr u32 r = decltype(rc)::value;
+            const u32 x = (q << REG_BITS) | r;
+            const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;
+            u32 lo, hi;
+            if (SHIFT) {
+                lo = (u32)((const uint8_t*)a.metrics_in)[(size_t)fA * N + s] << 8;
+                hi = (u32)((const uint8_t*)a.metrics_in)[(size_t)fB * N + s] << 8;
+            } else {
+                lo = ((const uint16_t*)a.metrics_in)[(size_t)fA * N + s];
+                hi = ((const uint16_t*)a.metrics_in)[(size_t)fB * N + s];
+            }
+            m[r] = (lo | (hi << 16)) ^ BIAS2;
+        });
+    } else {
         const u32 sA = a.start_state ? (a.start_state[fA] & SP::SMASK) : 0u;
         const u32 sB = a.start_state ? (a.start_state[fB] & SP::SMASK) : 0u;
         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
@@ -311,11 +358,18 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         });
     }
 
+    // the unrolled block that holds step t_begin starts at step tb0 (0 for a fresh decode)
+    const u32 tb0 = T_BEGIN - T_BEGIN % (u32)U;
     uint4 cA[NCH ? NCH : 1], cB[NCH ? NCH : 1];
     static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
         constexpr int c = decltype(cc)::value;
-        cA[c] = load_chunk(rsrc, offA + 16 * c, misA, fix);
-        cB[c] = load_chunk(rsrc, offB + 16 * c, misB, fix);
+        if constexpr (RESUME) {
+            cA[c] = load_chunk_entry(rsrc, offA + tb0 * BPS + 16 * c, misA, fix);
+            cB[c] = load_chunk_entry(rsrc, offB + tb0 * BPS + 16 * c, misB, fix);
+        } else {
+            cA[c] = load_chunk(rsrc, offA + 16 * c, misA, fix);
+            cB[c] = load_chunk(rsrc, offB + 16 * c, misB, fix);
+        }
     });
     // LDSBM: symbols of this lane's step of the next NG groups (register ring, slot = group % NG)
     u32 gA[NG][NDW], gB[NG][NDW];
@@ -424,16 +478,23 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         });
     };
     if constexpr (LDSBM) {
-        static_for<NG>([&](auto sc) __attribute__((always_inline)) { load_group((u32)(decltype(sc)::value * GROUP), sc); });
+        static_for<NG>([&](auto sc) __attribute__((always_inline)) { load_group(tb0 + (u32)(decltype(sc)::value * GROUP), sc); });
         bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        load_group((u32)(NG * GROUP), std::integral_constant<int, 0>{});
+        load_group(tb0 + (u32)(NG * GROUP), std::integral_constant<int, 0>{});
         bm_fetch(std::integral_constant<int, 0>{});
     } else {
         branch_metrics(std::integral_constant<int, 0>{});
     }
+    if constexpr (DW != 4 && RESUME) {
+        // resuming inside a 16-byte decision row: keep the steps an earlier call already wrote
+        if (T_BEGIN % SPS != 0) {
+            const uint4 v = ws_tile[(size_t)(T_BEGIN / SPS) * 64 + lane];
+            dq[0] = v.x; dq[1] = v.y; dq[2] = v.z; dq[3] = v.w;
+        }
+    }
 
-    u32 t0 = 0;
-    uint4* ws_blk = ws_tile;   // wave-uniform: decision rows of the current block (U is a multiple of SPS)
+    u32 t0 = tb0;
+    uint4* ws_blk = ws_tile + (size_t)(tb0 / SPS) * 64;   // wave-uniform: decision rows of the current block (U is a multiple of SPS)
     // one unrolled block of U trellis steps; `guarded` adds the per-step bound check needed only by the last, partial block
     auto block = [&](auto guarded_c) __attribute__((always_inline)) {
         constexpr bool GUARDED = decltype(guarded_c)::value;
@@ -441,7 +502,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             constexpr int u = decltype(uc)::value;
             constexpr int PH = u % SB;
             constexpr int cur = u & 1;
-            if (!GUARDED || t0 + u < a.n_steps) {
+            if (!GUARDED || t0 + u < a.t_end) {
                 if constexpr (LDSBM) {
                     if constexpr (u % GROUP == 0) {
                         // first step of block group Jb: produce group Jb + 1, then refill its symbol slot with group Jb + 1 + NG
@@ -461,7 +522,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     constexpr int first_use = (16 * c) / BPS;
                     static_assert(last_use >= 1, "a 16-byte chunk spans at least two steps");
                     if constexpr (last_use - 1 == u) {
-                        if (t0 + U + first_use < a.n_steps) {
+                        if (t0 + U + first_use < a.t_end) {
                             const u32 o = (t0 + U) * BPS + 16 * c;
                             cA[c] = load_chunk(rsrc, offA + o, misA, fix);
                             cB[c] = load_chunk(rsrc, offB + o, misB, fix);
@@ -469,6 +530,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     }
                 });
 
+                // a resumed call enters its first block in the middle: the steps below t_begin only keep the look-ahead
+                // pipeline above running
+                if (!GUARDED || !RESUME || t0 + u >= T_BEGIN) {
                 constexpr bool LP = SP::lane_phase(PH);
                 constexpr int PB = LP ? T : SP::pbit(PH);          // register bit the butterflies pair on
                 constexpr int LB = LP ? SP::pbit(PH) - REG_BITS : 0;
@@ -586,24 +650,34 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         rsB += (uint64_t)((sub >> 16) >> SHIFT);
                     }
                 }
+                }
             }
         });
     };
-    for (; t0 + U <= a.n_steps; t0 += U, ws_blk += (U / SPS) * 64) block(std::false_type{});
-    if (t0 < a.n_steps) block(std::true_type{});
+    // whole blocks run unguarded; the (at most two) partial ones -- the entry block of a resumed call, the last block of any
+    // call -- share ONE guarded copy of the unrolled body
+    if constexpr (RESUME) {
+        for (; t0 < a.t_end; t0 += U, ws_blk += (U / SPS) * 64) {
+            if (t0 >= T_BEGIN && t0 + U <= a.t_end) block(std::false_type{});
+            else block(std::true_type{});
+        }
+    } else {
+        for (; t0 + U <= a.t_end; t0 += U, ws_blk += (U / SPS) * 64) block(std::false_type{});
+        if (t0 < a.t_end) block(std::true_type{});
+    }
 
     if constexpr (DW != 4) {
-        if (a.n_steps % SPS != 0) ws_tile[(size_t)(a.n_steps / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+        if (a.t_end % SPS != 0) ws_tile[(size_t)(a.t_end / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
     }
 
     // ---- final metrics in state order (get_error / m_metrics "old" buffer) ----
     if (a.metrics_out) {
-        const int ph = (int)(a.n_steps % SB);
+        const int ph = (int)(a.t_end % SB);
         constexpr size_t N = (size_t)1 << SB;
         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
             constexpr u32 r = decltype(rc)::value;
             const u32 x = (q << REG_BITS) | r;
-            const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;   // state held by slot x after n_steps steps
+            const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;   // state held by slot x after step t_end - 1
             const u32 v = m[r] ^ BIAS2;
             if (SHIFT) {
                 if (validA) ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
@@ -992,7 +1066,9 @@ VIT_DEV void reg_export_body(const RegExportArgs& a) {
 template <class SP>
 constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 : 2; }
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT>(a); }
+__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, false>(a); }
+template <class SP, int SHIFT>
+__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_resume_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, true>(a); }
 
 // chainback: one kernel name per code, the body is picked by the code's geometry
 template <class SP>
@@ -1022,6 +1098,7 @@ using Spec_K5R2 = RegSpec<5, 2, 23, 25, 0, 0, 0>;           // Basic K=5        
 struct RegJitModule {
     hipModule_t module = nullptr;
     hipFunction_t update[2] = {nullptr, nullptr};   // [0] 16-bit, [1] 8-bit metrics/symbols
+    hipFunction_t resume[2] = {nullptr, nullptr};
     hipFunction_t chainback = nullptr, export_ = nullptr;
     unsigned chainback_frames_per_block = 32;
 };
@@ -1079,8 +1156,13 @@ template <int ID> int reg_launch_export(const RegExportArgs& a, unsigned blocks,
 #ifdef VIT_REG_ID
 template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
-    if (shift) hipLaunchKernelGGL((reg_update_kernel<SP, 8>), dim3(tiles), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((reg_update_kernel<SP, 0>), dim3(tiles), dim3(64), 0, st, a);
+    if (a.metrics_in) {
+        if (shift) hipLaunchKernelGGL((reg_resume_kernel<SP, 8>), dim3(tiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((reg_resume_kernel<SP, 0>), dim3(tiles), dim3(64), 0, st, a);
+    } else {
+        if (shift) hipLaunchKernelGGL((reg_update_kernel<SP, 8>), dim3(tiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((reg_update_kernel<SP, 0>), dim3(tiles), dim3(64), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
@@ -1123,25 +1205,32 @@ inline int reg_jit_launch(hipFunction_t fn, const void* args, size_t args_bytes,
     return hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, st, nullptr, config) == hipSuccess ? 0 : -1;
 }
 
-inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t frames,
-                      size_t n_steps, size_t L, void* d_ws, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start,
-                      hipStream_t st) {
+// steps [first_step, first_step + n_steps) of every frame.  d_metrics_in == null: reset(start_state) (first_step must be 0);
+// else resume from those metrics.  sym_stride: soft_t elements between the chunks of consecutive frames.
+inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const void* d_symbols, size_t sym_stride, size_t frames,
+                      size_t first_step, size_t n_steps, size_t L, void* d_ws, const void* d_metrics_in, void* d_metrics,
+                      uint64_t* d_renorm, const uint32_t* d_start, hipStream_t st) {
     if (frames == 0 || n_steps == 0) return 0;
     RegUpdateArgs a{};
     a.symbols = (const uint8_t*)d_symbols;
-    a.sym_frame_stride_bytes = n_steps * (size_t)rc.R * (shift ? 1 : 2);
-    if (a.sym_frame_stride_bytes * (size_t)rc.tile >= 0xFFFFFFFFull) return -2;   // per-lane 32-bit buffer offsets
-    a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
+    a.sym_frame_stride_bytes = sym_stride * (shift ? 1 : 2);
+    // per-lane 32-bit buffer offsets; a resumed call's look-ahead may form slightly negative offsets (see reg_update_body):
+    // they must stay distinguishable from valid ones (sign bit) and out of the descriptor's range
+    if (a.sym_frame_stride_bytes * (size_t)rc.tile + 65536 >= (d_metrics_in ? 0x7FFF0000ull : 0xFFFF0000ull)) return -2;
+    // the last frame's chunk ends n_steps into its stride
+    a.sym_total_bytes = (frames - 1) * a.sym_frame_stride_bytes + n_steps * (size_t)rc.R * (shift ? 1 : 2);
     a.ws = (uint4*)d_ws;
     a.ws_tile_stride = reg_groups(rc, L) * 64;
     a.metrics_out = d_metrics;
     a.renorm_sum = d_renorm;
     a.start_state = d_start;
+    a.metrics_in = d_metrics_in;
     a.frames = (u32)frames;
-    a.n_steps = (u32)n_steps;
+    a.t_begin = (u32)first_step;
+    a.t_end = (u32)(first_step + n_steps);
     a.cfg = cfg;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
-    if (rc.jit) return reg_jit_launch(rc.jit->update[shift ? 1 : 0], &a, sizeof(a), tiles, 64, st);
+    if (rc.jit) return reg_jit_launch((d_metrics_in ? rc.jit->resume : rc.jit->update)[shift ? 1 : 0], &a, sizeof(a), tiles, 64, st);
     switch (rc.id) {
         case 0: return reg_launch_update<0>(shift, a, tiles, st);
         case 1: return reg_launch_update<1>(shift, a, tiles, st);

@@ -4,15 +4,21 @@
 // instantiation.  On first use we write a four-kernel translation unit that includes kernels_reg.hpp with the caller's
 // polynomials, compile it with `hipcc --genco` for gfx950 (about as long as one of the ahead-of-time units: 10-40 s),
 // keep the code object in a disk cache and load it with hipModuleLoad.  Later handles -- and later processes -- reuse it.
-//   cache directory : $VIT_HIP_CACHE_DIR, else $HOME/.cache/vit_hip, else /tmp/vit_hip_cache
-//   compiler        : $VIT_HIP_HIPCC, else /opt/rocm/bin/hipcc
+//   cache directory : $VIT_HIP_CACHE_DIR, else $XDG_CACHE_HOME/vit_hip, else $HOME/.cache/vit_hip, else /tmp/vit_hip_cache-<uid>;
+//                     created 0700 and used only if it belongs to this user and nobody else can write to it -- a code
+//                     object found there is loaded into the caller's GPU context, so it must not be plantable by others
+//   compiler        : $VIT_HIP_HIPCC, else /opt/rocm/bin/hipcc; started with posix_spawn and an argv array (a fresh child
+//                     process, no shell); its version string and the target arch are part of the cache key
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <spawn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <fstream>
@@ -20,8 +26,11 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "kernels_reg.hpp"
+
+extern char** environ;
 
 namespace vit {
 
@@ -39,21 +48,68 @@ inline std::string this_library_dir() {
     return ".";
 }
 
+// owned by this user, not writable by group or others, and of the expected kind
+inline bool private_to_user(const std::string& path, bool want_dir) {
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) return false;
+    if (want_dir ? !S_ISDIR(st.st_mode) : !S_ISREG(st.st_mode)) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
+inline bool make_private_dir(const std::string& d) {
+    const size_t slash = d.find_last_of('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0700);   // e.g. ~/.cache
+    (void)mkdir(d.c_str(), 0700);
+    return private_to_user(d, true) && access(d.c_str(), W_OK) == 0;
+}
+
+// empty string: no usable private directory (the caller then refuses to JIT rather than trust a shared one)
 inline std::string cache_dir() {
     const char* e = getenv("VIT_HIP_CACHE_DIR");
+    if (e && *e) return make_private_dir(e) ? std::string(e) : std::string();
     std::string d;
-    if (e && *e) d = e;
-    else if ((e = getenv("HOME")) && *e) d = std::string(e) + "/.cache/vit_hip";
-    else d = "/tmp/vit_hip_cache";
-    // mkdir -p (two levels are enough for the defaults)
-    const size_t slash = d.find_last_of('/');
-    if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0755);
-    (void)mkdir(d.c_str(), 0755);
-    if (access(d.c_str(), W_OK) != 0) {
-        d = "/tmp/vit_hip_cache";
-        (void)mkdir(d.c_str(), 0755);
+    if ((e = getenv("XDG_CACHE_HOME")) && *e) { d = std::string(e) + "/vit_hip"; if (make_private_dir(d)) return d; }
+    if ((e = getenv("HOME")) && *e) { d = std::string(e) + "/.cache/vit_hip"; if (make_private_dir(d)) return d; }
+    d = "/tmp/vit_hip_cache-" + std::to_string((unsigned long)geteuid());
+    return make_private_dir(d) ? d : std::string();
+}
+
+// run argv[0] with argv (no shell), stdout+stderr to `log_path` (or captured into *out when non-null); returns exit status
+inline int run_child(const std::vector<std::string>& argv, const std::string& log_path, std::string* out) {
+    std::vector<char*> av;
+    for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    int pipefd[2] = {-1, -1};
+    if (out) {
+        if (pipe(pipefd) != 0) { posix_spawn_file_actions_destroy(&fa); return -1; }
+        posix_spawn_file_actions_adddup2(&fa, pipefd[1], 1);
+        posix_spawn_file_actions_adddup2(&fa, pipefd[1], 2);
+        posix_spawn_file_actions_addclose(&fa, pipefd[0]);
+    } else {
+        posix_spawn_file_actions_addopen(&fa, 1, log_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        posix_spawn_file_actions_adddup2(&fa, 1, 2);
     }
-    return d;
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (out) close(pipefd[1]);
+    if (rc != 0) { if (out) close(pipefd[0]); return -1; }
+    if (out) {
+        char buf[512];
+        ssize_t n;
+        while ((n = read(pipefd[0], buf, sizeof(buf))) > 0) out->append(buf, (size_t)n);
+        close(pipefd[0]);
+    }
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return -1;
+    return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+inline uint64_t fnv1a_str(const std::string& s, uint64_t h) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
 }
 
 inline uint64_t fnv1a_file(const std::string& path, uint64_t h) {
@@ -77,23 +133,39 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
     if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5,7,9}, R <= 4"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
+    const char* cc_env = getenv("VIT_HIP_HIPCC");
+    const std::string hipcc = cc_env && *cc_env ? cc_env : "/opt/rocm/bin/hipcc";
+    const std::string arch = "gfx950";
+    std::lock_guard<std::mutex> lock(mutex());
+    // compiler identity: once per process
+    static std::string cc_version;
+    if (cc_version.empty()) {
+        if (run_child({hipcc, "--version"}, "", &cc_version) != 0 || cc_version.empty()) {
+            cc_version.clear();
+            err = "cannot run " + hipcc + " --version";
+            return nullptr;
+        }
+    }
     uint64_t h = 1469598103934665603ull;
     h = fnv1a_file(src_dir + "/kernels_reg.hpp", h);
     h = fnv1a_file(src_dir + "/common.hpp", h);
     if (h == 1469598103934665603ull) { err = "kernel sources not found next to the library (" + src_dir + ")"; return nullptr; }
+    h = fnv1a_str(cc_version, h);
+    h = fnv1a_str(arch, h);
     std::ostringstream key;
     key << "reg_K" << K << "R" << R;
     for (int i = 0; i < 4; ++i) key << "_" << (i < R ? G[i] : 0u);
-    key << "_" << std::hex << h;
-    std::lock_guard<std::mutex> lock(mutex());
+    key << "_" << arch << "_" << std::hex << h;
     const std::string mkey = key.str() + "@" + std::to_string(device);
     auto it = modules().find(mkey);
     if (it != modules().end()) return it->second;
 
     const std::string dir = cache_dir();
+    if (dir.empty()) { err = "no private cache directory for run-time compiled kernels (set VIT_HIP_CACHE_DIR to a directory only you can write)"; return nullptr; }
     const std::string base = dir + "/" + key.str();
     const std::string hsaco = base + ".hsaco";
-    if (access(hsaco.c_str(), R_OK) != 0) {
+    if (!private_to_user(hsaco, false)) {
+        (void)unlink(hsaco.c_str());                 // not ours or writable by others: never load it
         const std::string src = base + "." + std::to_string((long)getpid()) + ".hip";
         {
             std::ofstream f(src);
@@ -101,27 +173,29 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
               << "using SP = vit::RegSpec<" << K << ", " << R;
             for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
             f << ", " << lane_bits << ">;\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, false>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, false>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, 2) vit_jit_chainback(vit::RegChainbackArgs a) { vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
         }
-        const char* cc = getenv("VIT_HIP_HIPCC");
         const std::string tmp = hsaco + "." + std::to_string((long)getpid()) + ".tmp";
-        const std::string cmd = std::string(cc && *cc ? cc : "/opt/rocm/bin/hipcc") +
-                                " -O3 -std=c++17 --offload-arch=gfx950 --genco -o '" + tmp + "' '" + src + "' > '" + base + ".log' 2>&1";
-        const int rc = system(cmd.c_str());
+        const int rc = run_child({hipcc, "-O3", "-std=c++17", "--offload-arch=" + arch, "--genco", "-o", tmp, src}, base + ".log", nullptr);
         if (rc != 0 || access(tmp.c_str(), R_OK) != 0) {
             err = "hipcc failed for the run-time PLAN_REG instantiation (see " + base + ".log)";
             return nullptr;
         }
+        (void)chmod(tmp.c_str(), 0600);
         (void)rename(tmp.c_str(), hsaco.c_str());
         (void)unlink(src.c_str());
     }
     RegJitModule* m = new RegJitModule();
-    if (hipModuleLoad(&m->module, hsaco.c_str()) != hipSuccess ||
+    if (!private_to_user(hsaco, false) || hipModuleLoad(&m->module, hsaco.c_str()) != hipSuccess ||
         hipModuleGetFunction(&m->update[0], m->module, "vit_jit_update_16") != hipSuccess ||
         hipModuleGetFunction(&m->update[1], m->module, "vit_jit_update_8") != hipSuccess ||
+        hipModuleGetFunction(&m->resume[0], m->module, "vit_jit_resume_16") != hipSuccess ||
+        hipModuleGetFunction(&m->resume[1], m->module, "vit_jit_resume_8") != hipSuccess ||
         hipModuleGetFunction(&m->chainback, m->module, "vit_jit_chainback") != hipSuccess ||
         hipModuleGetFunction(&m->export_, m->module, "vit_jit_export") != hipSuccess) {
         err = "could not load " + hsaco;

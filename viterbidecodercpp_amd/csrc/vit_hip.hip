@@ -3,8 +3,10 @@
 // point fails with VIT_HIP_ERR_NO_DEVICE / VIT_HIP_ERR_RUNTIME.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <string.h>
 
 #include <string>
@@ -14,6 +16,7 @@
 #include "kernels_lds.hpp"
 #include "kernels_lds2.hpp"
 #include "kernels_reg.hpp"
+#include "kernels_synth.hpp"
 #include "reg_jit.hpp"
 
 namespace {
@@ -117,14 +120,14 @@ int launch_lds_update_r(int R, const vit::LdsUpdateArgs& a, size_t frames, int N
 }
 
 // decisions in the reference layout [F][rows][W]; rows = L + K-1
-int lds_update(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t rows, uint32_t row0,
-               uint64_t* d_decisions, void* d_metrics, bool reset, uint64_t* d_renorm, const uint32_t* d_start,
+int lds_update(vit_hip_handle h, const void* d_symbols, size_t sym_stride, size_t frames, size_t n_steps, size_t rows,
+               uint32_t row0, uint64_t* d_decisions, void* d_metrics, bool reset, uint64_t* d_renorm, const uint32_t* d_start,
                hipStream_t st) {
     if (frames == 0 || n_steps == 0) return VIT_HIP_OK;
     vit::LdsUpdateArgs a{};
     a.symbols = (const uint8_t*)d_symbols;
-    a.sym_frame_stride_bytes = n_steps * (size_t)h->R * (size_t)h->soft_bytes;
-    a.sym_total_bytes = frames * a.sym_frame_stride_bytes;
+    a.sym_frame_stride_bytes = sym_stride * (size_t)h->soft_bytes;
+    a.sym_total_bytes = (frames - 1) * a.sym_frame_stride_bytes + n_steps * (size_t)h->R * (size_t)h->soft_bytes;
     a.decisions = d_decisions;
     a.dec_frame_stride_words = rows * (size_t)h->W;
     a.dec_row0 = row0;
@@ -228,6 +231,32 @@ __global__ void depuncture_kernel(const T* __restrict__ in, size_t in_stride, co
             if (k0 + i < n_out) dst[i] = v[i];
     }
 }
+// ViterbiDecoder_Core::reset (core.h:202-211) for a batch: metrics [F][N] error_t
+template <typename error_t>
+__global__ void reset_kernel(error_t* met, const uint32_t* start, size_t frames, uint32_t N, uint32_t init_start, uint32_t init_non_start) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= frames * N) return;
+    const size_t f = idx / N;
+    const uint32_t s = (uint32_t)(idx % N);
+    const uint32_t st = start ? (start[f] & (N - 1u)) : 0u;
+    met[idx] = (error_t)(s == st ? init_start : init_non_start);
+}
+
+template <typename soft_t>
+int launch_synth(int R, const SynthArgs& a, unsigned blocks, hipStream_t st) {
+    switch (R) {
+        case 1: hipLaunchKernelGGL((synth_kernel<soft_t, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((synth_kernel<soft_t, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((synth_kernel<soft_t, 3>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((synth_kernel<soft_t, 4>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((synth_kernel<soft_t, 5>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 6: hipLaunchKernelGGL((synth_kernel<soft_t, 6>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 7: hipLaunchKernelGGL((synth_kernel<soft_t, 7>), dim3(blocks), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((synth_kernel<soft_t, 8>), dim3(blocks), dim3(256), 0, st, a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 }  // namespace vit
 
 extern "C" {
@@ -240,7 +269,7 @@ int vit_hip_device_count(void) {
     return n;
 }
 
-int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+static int vit_hip_create_impl(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
                    int device, vit_hip_handle* out) {
     if (!out) return fail(VIT_HIP_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
@@ -347,7 +376,7 @@ int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
     return VIT_HIP_OK;
 }
 
-int vit_hip_set_plan(vit_hip_handle h, int plan) {
+static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
     if (plan == VIT_HIP_PLAN_REG && !h->reg_ok) {
@@ -366,7 +395,7 @@ int vit_hip_set_plan(vit_hip_handle h, int plan) {
 }
 
 size_t vit_hip_blob_bytes(int K, int R, int soft_bytes, int error_bytes) {
-    if (K < 2 || K > 30 || R < 1) return 0;
+    if (K < 2 || K > 30 || R < 1 || R > 64 || soft_bytes < 1 || soft_bytes > 8 || error_bytes < 1 || error_bytes > 8) return 0;
     const size_t Ht = K > 2 ? ((size_t)1 << (K - 2)) : 1;
     return sizeof(BlobHeader) + (size_t)R * Ht * (size_t)soft_bytes + 4 * (size_t)error_bytes;
 }
@@ -385,11 +414,15 @@ int vit_hip_pack_blob(int K, int R, int soft_bytes, int error_bytes, const void*
     return VIT_HIP_OK;
 }
 
-int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vit_hip_handle* out) {
+static int vit_hip_create_from_blob_impl(const void* blob, size_t blob_bytes, int device, vit_hip_handle* out) {
     if (!blob || blob_bytes < sizeof(BlobHeader)) return fail(VIT_HIP_ERR_INVALID_ARG, "blob too small");
     BlobHeader hd;
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != BLOB_MAGIC) return fail(VIT_HIP_ERR_INVALID_ARG, "bad blob magic");
+    // the header is untrusted: validate before any size arithmetic
+    if (hd.K < 2 || hd.K > 15 || hd.R < 1 || hd.R > 8 ||
+        !((hd.soft_bytes == 2 && hd.error_bytes == 2) || (hd.soft_bytes == 1 && hd.error_bytes == 1)))
+        return fail(VIT_HIP_ERR_INVALID_ARG, "corrupt blob header");
     const size_t need = vit_hip_blob_bytes(hd.K, hd.R, hd.soft_bytes, hd.error_bytes);
     if (!need || blob_bytes < need) return fail(VIT_HIP_ERR_INVALID_ARG, "blob truncated");
     const uint8_t* p = (const uint8_t*)blob + sizeof(hd);
@@ -408,34 +441,58 @@ size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L) {
     return align_up(frames * (L + (size_t)h->K - 1) * (size_t)h->W * 8, 256);
 }
 
-int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t L,
-                         void* d_workspace, size_t workspace_bytes, void* d_final_metrics, uint64_t* d_renorm_sum,
-                         const uint32_t* d_start_state, vit_hip_stream_t stream) {
+namespace {
+// reset + update (d_metrics_in == null, first_step == 0) or resumed update: one body behind both entry points
+int update_batch_impl(vit_hip_handle h, const void* d_symbols, size_t sym_stride, size_t frames, size_t first_step, size_t n_steps,
+                      size_t L, void* d_workspace, size_t workspace_bytes, const void* d_metrics_in, void* d_metrics_out,
+                      uint64_t* d_renorm_sum, const uint32_t* d_start_state, vit_hip_stream_t stream) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (frames == 0) return VIT_HIP_OK;
     if (!d_symbols || !d_workspace) return fail(VIT_HIP_ERR_INVALID_ARG, "d_symbols/d_workspace is NULL");
-    if (n_steps > L + (size_t)h->K - 1) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps exceeds traceback length + K-1");
+    if (first_step + n_steps > L + (size_t)h->K - 1) return fail(VIT_HIP_ERR_INVALID_ARG, "steps exceed traceback length + K-1");
     if (n_steps > 0x7FFFFFF0u || frames > 0x7FFFFFF0u) return fail(VIT_HIP_ERR_INVALID_ARG, "batch too large");
+    if (sym_stride == 0) sym_stride = n_steps * (size_t)h->R;
+    if (sym_stride < n_steps * (size_t)h->R) return fail(VIT_HIP_ERR_INVALID_ARG, "symbol_frame_stride shorter than one chunk");
     if (workspace_bytes < vit_hip_workspace_bytes(h, frames, L)) return fail(VIT_HIP_ERR_WORKSPACE, "workspace too small");
     if (((uintptr_t)d_workspace & 255u) != 0) return fail(VIT_HIP_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     if (h->soft_bytes == 2 && ((uintptr_t)d_symbols & 1u)) return fail(VIT_HIP_ERR_INVALID_ARG, "int16 symbols must be 2-byte aligned");
+    if (n_steps == 0) return VIT_HIP_OK;
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (h->plan == VIT_HIP_PLAN_REG) {
-        const int rc = vit::reg_update(h->reg_code, h->cfg, h->shift, d_symbols, frames, n_steps, L, d_workspace,
-                                       d_final_metrics, d_renorm_sum, d_start_state, st);
-        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan update launch failed");
+        const int rc = vit::reg_update(h->reg_code, h->cfg, h->shift, d_symbols, sym_stride, frames, first_step, n_steps, L,
+                                       d_workspace, d_metrics_in, d_metrics_out, d_renorm_sum, d_start_state, st);
+        if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, rc == -2 ? "register-plan update: a tile's symbols exceed 32-bit offsets"
+                                                                : "register-plan update launch failed");
         return VIT_HIP_OK;
     }
     if (h->plan == VIT_HIP_PLAN_LDS2) {
-        const int rc = vit::lds2_update(h->K, h->R, h->cfg, h->shift, h->d_pattern, d_symbols, frames, n_steps, L, d_workspace,
-                                        d_final_metrics, d_renorm_sum, d_start_state, st);
+        const int rc = vit::lds2_update(h->K, h->R, h->cfg, h->shift, h->d_pattern, d_symbols, sym_stride, frames, first_step,
+                                        n_steps, L, d_workspace, d_metrics_in, d_metrics_out, d_renorm_sum, d_start_state, st);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "PLAN_LDS2 update launch failed");
         return VIT_HIP_OK;
     }
-    return lds_update(h, d_symbols, frames, n_steps, L + (size_t)h->K - 1, 0, (uint64_t*)d_workspace, d_final_metrics,
-                      true, d_renorm_sum, d_start_state, st);
+    // PLAN_LDS reads and writes its metrics through one buffer
+    if (d_metrics_in && d_metrics_in != d_metrics_out) return fail(VIT_HIP_ERR_INVALID_ARG, "PLAN_LDS resumes in place");
+    return lds_update(h, d_symbols, sym_stride, frames, n_steps, L + (size_t)h->K - 1, (uint32_t)first_step, (uint64_t*)d_workspace,
+                      d_metrics_out, d_metrics_in == nullptr, d_renorm_sum, d_start_state, st);
+}
+}  // namespace
+
+int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t n_steps, size_t L,
+                         void* d_workspace, size_t workspace_bytes, void* d_final_metrics, uint64_t* d_renorm_sum,
+                         const uint32_t* d_start_state, vit_hip_stream_t stream) {
+    return update_batch_impl(h, d_symbols, 0, frames, 0, n_steps, L, d_workspace, workspace_bytes, nullptr, d_final_metrics,
+                             d_renorm_sum, d_start_state, stream);
+}
+
+int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t symbol_frame_stride, size_t frames,
+                                size_t first_step, size_t n_steps, size_t L, void* d_workspace, size_t workspace_bytes,
+                                void* d_metrics_inout, uint64_t* d_renorm_sum, vit_hip_stream_t stream) {
+    if (!d_metrics_inout) return fail(VIT_HIP_ERR_INVALID_ARG, "d_metrics_inout is NULL (vit_hip_reset_batch fills it for step 0)");
+    return update_batch_impl(h, d_symbols, symbol_frame_stride, frames, first_step, n_steps, L, d_workspace, workspace_bytes,
+                             d_metrics_inout, d_metrics_inout, d_renorm_sum, nullptr, stream);
 }
 
 int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
@@ -519,6 +576,160 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
     return VIT_HIP_OK;
 }
 
+// ---- RCCL broadcast of the shared table (the one collective of the multi-GPU path) ----
+namespace {
+typedef int (*nccl_broadcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void* /*ncclComm_t*/, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+struct RcclApi {
+    nccl_broadcast_fn broadcast = nullptr;
+    nccl_errstr_fn errstr = nullptr;
+};
+// The communicator belongs to the RCCL the host program uses: take the symbol from the process first (a C/C++ host that
+// links -lrccl), and load librccl.so only when the process does not export it.
+const RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+        void* lib = nullptr;
+        if (!sym) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
+            if (lib) sym = dlsym(lib, "ncclBroadcast");
+        }
+        api.broadcast = (nccl_broadcast_fn)sym;
+        api.errstr = (nccl_errstr_fn)(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    }
+    return api.broadcast ? &api : nullptr;
+}
+}  // namespace
+
+static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
+                            void* branch_table, void* config, int device, vit_hip_stream_t stream) {
+    if (!nccl_comm || !branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    if (K < 2 || K > 15 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "unsupported (K, R, soft_t, error_t)");
+    const size_t need = vit_hip_blob_bytes(K, R, soft_bytes, error_bytes);
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(VIT_HIP_ERR_RUNTIME, "RCCL not available: ncclBroadcast is neither in the process nor in librccl.so");
+    std::vector<uint8_t> blob(need);
+    if (rank == root) {
+        const int rc = vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need);
+        if (rc != VIT_HIP_OK) return rc;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    void* d_buf = nullptr;
+    VIT_HIP_CHECK(hipMalloc(&d_buf, need));
+    int result = VIT_HIP_OK;
+    do {
+        if (rank == root && hipMemcpyAsync(d_buf, blob.data(), need, hipMemcpyHostToDevice, st) != hipSuccess) {
+            result = fail(VIT_HIP_ERR_RUNTIME, "hipMemcpyAsync (blob to device) failed");
+            break;
+        }
+        const int nrc = api->broadcast(d_buf, d_buf, need, 1 /* ncclUint8 */, root, nccl_comm, st);
+        if (nrc != 0) {
+            result = fail(VIT_HIP_ERR_RUNTIME, std::string("ncclBroadcast: ") + (api->errstr ? api->errstr(nrc) : "error"));
+            break;
+        }
+        if (hipMemcpyAsync(blob.data(), d_buf, need, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            result = fail(VIT_HIP_ERR_RUNTIME, "copying the broadcast blob back failed");
+            break;
+        }
+    } while (false);
+    (void)hipFree(d_buf);
+    if (result != VIT_HIP_OK) return result;
+    BlobHeader hd;
+    memcpy(&hd, blob.data(), sizeof(hd));
+    if (hd.magic != BLOB_MAGIC || hd.K != K || hd.R != R || hd.soft_bytes != soft_bytes || hd.error_bytes != error_bytes)
+        return fail(VIT_HIP_ERR_INVALID_ARG, "the root rank broadcast a table for a different (K, R, soft_t, error_t)");
+    if (rank != root) {
+        const size_t tb = need - sizeof(hd) - 4 * (size_t)error_bytes;
+        memcpy(branch_table, blob.data() + sizeof(hd), tb);
+        memcpy(config, blob.data() + sizeof(hd) + tb, 4 * (size_t)error_bytes);
+    }
+    return VIT_HIP_OK;
+}
+
+int vit_hip_reset_batch(vit_hip_handle h, size_t frames, const uint32_t* d_start_state, void* d_metrics,
+                        vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0) return VIT_HIP_OK;
+    if (!d_metrics) return fail(VIT_HIP_ERR_INVALID_ARG, "d_metrics is NULL");
+    const size_t total = frames * (size_t)h->N;
+    if (total > 0x7FFFFFFFull * 256ull) return fail(VIT_HIP_ERR_INVALID_ARG, "batch too large for one launch");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (h->error_bytes == 2)
+        hipLaunchKernelGGL(vit::reset_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (uint16_t*)d_metrics, d_start_state,
+                           frames, (uint32_t)h->N, h->cfg_raw[1], h->cfg_raw[2]);
+    else
+        hipLaunchKernelGGL(vit::reset_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (uint8_t*)d_metrics, d_start_state,
+                           frames, (uint32_t)h->N, h->cfg_raw[1], h->cfg_raw[2]);
+    VIT_HIP_CHECK(hipGetLastError());
+    return VIT_HIP_OK;
+}
+
+int vit_hip_synth_batch(vit_hip_handle h, size_t frames, size_t L, uint64_t seed, uint64_t first_frame, float ebn0_db,
+                        int noise_free, uint8_t* d_tx_bytes, void* d_symbols, vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (frames == 0) return VIT_HIP_OK;
+    if (!d_symbols) return fail(VIT_HIP_ERR_INVALID_ARG, "d_symbols is NULL");
+    if (L % 8 != 0) return fail(VIT_HIP_ERR_INVALID_ARG, "L must be a multiple of 8 (whole info bytes)");
+    if (!h->linear) return fail(VIT_HIP_ERR_UNSUPPORTED, "the branch table is not that of a convolutional code (no polynomials)");
+    if (h->soft_bytes == 2 && ((uintptr_t)d_symbols & 1u)) return fail(VIT_HIP_ERR_INVALID_ARG, "int16 symbols must be 2-byte aligned");
+    const size_t S = L + (size_t)h->K - 1;
+    const size_t chunks = (S + 7) / 8;
+    if (frames > 0xFFFFFFFFull || S > 0x0FFFFFFFull || chunks * frames > 0x7FFFFFFFull * 256ull)
+        return fail(VIT_HIP_ERR_INVALID_ARG, "batch too large for one launch");
+    vit::SynthArgs a{};
+    a.tx = d_tx_bytes;
+    a.symbols = d_symbols;
+    a.seed = seed;
+    a.first_frame = first_frame;
+    a.frames = (uint32_t)frames; a.L = (uint32_t)L; a.S = (uint32_t)S; a.K = (uint32_t)h->K; a.R = (uint32_t)h->R;
+    for (int i = 0; i < h->R && i < 8; ++i) a.G[i] = h->G[i];
+    a.high = h->high; a.low = h->low;
+    a.noise_free = noise_free ? 1 : 0;
+    // run_snr_ber.cpp:311-330, in float like the reference
+    const float EsNo_dB = ebn0_db - 10.0f * log10f((float)h->R);
+    const float noise_variance = powf(10.0f, -(EsNo_dB + 3.0f) / 10.0f);
+    a.sigma = sqrtf(noise_variance);
+    a.mean = ((float)h->high + (float)h->low) / 2.0f;
+    a.scale = (((float)h->high - (float)h->low) / 2.0f) * (1.0f / sqrtf(1.0f + noise_variance));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    const unsigned blocks = (unsigned)((chunks * frames + 255) / 256);
+    const int rc = h->soft_bytes == 2 ? vit::launch_synth<int16_t>(h->R, a, blocks, (hipStream_t)stream)
+                                      : vit::launch_synth<int8_t>(h->R, a, blocks, (hipStream_t)stream);
+    if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "synth kernel launch failed");
+    return VIT_HIP_OK;
+}
+
+int vit_hip_count_bit_errors(vit_hip_handle h, const uint8_t* d_a, const uint8_t* d_b, size_t n_bytes, uint64_t* d_count,
+                             vit_hip_stream_t stream) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (n_bytes == 0) return VIT_HIP_OK;
+    if (!d_a || !d_b || !d_count) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL buffer");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    vit::BitErrArgs a{d_a, d_b, n_bytes, (unsigned long long*)d_count};
+    size_t blocks = (n_bytes / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vit::bit_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    VIT_HIP_CHECK(hipGetLastError());
+    return VIT_HIP_OK;
+}
+
 int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps,
                         uint64_t* decisions_out, uint64_t* renorm_sum_out) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
@@ -542,7 +753,7 @@ int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbo
     VIT_HIP_CHECK(hipMemcpyAsync(d_sym, symbols, n_steps * (size_t)h->R * (size_t)h->soft_bytes, hipMemcpyHostToDevice, h->stream));
     VIT_HIP_CHECK(hipMemcpyAsync(d_met, metrics_inout, (size_t)h->N * (size_t)h->error_bytes, hipMemcpyHostToDevice, h->stream));
     // streaming state lives on the host between calls, so this route always runs the LDS plan on one frame
-    rc = lds_update(h, d_sym, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
+    rc = lds_update(h, d_sym, n_steps * (size_t)h->R, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
     if (rc != VIT_HIP_OK) return rc;
     uint64_t rs = 0;
     VIT_HIP_CHECK(hipMemcpyAsync(decisions_out, d_dec, n_steps * (size_t)h->W * 8, hipMemcpyDeviceToHost, h->stream));
@@ -575,6 +786,34 @@ int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L
     VIT_HIP_CHECK(hipMemcpyAsync(bytes_out, base + dec_b, (L + 7) / 8, hipMemcpyDeviceToHost, h->stream));
     VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
     return VIT_HIP_OK;
+}
+
+// entry points that allocate on the host: no exception crosses the ABI
+#define VIT_HIP_NOTHROW(stmt)                                                                  \
+    try {                                                                                      \
+        stmt;                                                                                  \
+    } catch (const std::exception& e) {                                                        \
+        try { g_last_error = std::string("host exception: ") + e.what(); } catch (...) {}      \
+        return VIT_HIP_ERR_RUNTIME;                                                            \
+    } catch (...) {                                                                            \
+        return VIT_HIP_ERR_RUNTIME;                                                            \
+    }
+int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* branch_table, const void* config,
+                   int device, vit_hip_handle* out) {
+    VIT_HIP_NOTHROW(return vit_hip_create_impl(K, R, soft_bytes, error_bytes, branch_table, config, device, out));
+}
+
+int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vit_hip_handle* out) {
+    VIT_HIP_NOTHROW(return vit_hip_create_from_blob_impl(blob, blob_bytes, device, out));
+}
+
+int vit_hip_set_plan(vit_hip_handle h, int plan) {
+    VIT_HIP_NOTHROW(return vit_hip_set_plan_impl(h, plan));
+}
+
+int vit_hip_broadcast_table(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
+                            void* branch_table, void* config, int device, vit_hip_stream_t stream) {
+    VIT_HIP_NOTHROW(return vit_hip_broadcast_table_impl(nccl_comm, root, rank, K, R, soft_bytes, error_bytes, branch_table, config, device, stream));
 }
 
 }  // extern "C"

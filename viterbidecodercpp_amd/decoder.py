@@ -278,6 +278,43 @@ class BatchDecoder:
             C.c_void_p(ss.data_ptr()) if ss is not None else None, self._stream()))
         return met, rs
 
+    def reset_batch(self, frames: int, start_state=None, metrics_out=None):
+        """ViterbiDecoder_Core::reset for every frame (core.h:202-211): the device-resident metrics [F][N] a streamed decode
+        starts from."""
+        t = self.torch
+        edt = t.int16 if self.error_bytes == 2 else t.uint8
+        met = t.empty((frames, self.N), dtype=edt, device=self.device) if metrics_out is None else metrics_out
+        ss = None
+        if start_state is not None:
+            ss = t.as_tensor(start_state, dtype=t.int32, device=self.device).contiguous()
+        _lib.check(_lib.load().vit_hip_reset_batch(self._handle._h, frames, C.c_void_p(ss.data_ptr()) if ss is not None else None,
+                                                   C.c_void_p(met.data_ptr()), self._stream()))
+        return met
+
+    def update_resume(self, symbols, L: int, first_step: int, metrics, n_steps: int = None, symbol_frame_stride: int = 0,
+                      renorm_out=None, workspace=None):
+        """update() on decoders that already hold state (no reset): consumes `n_steps` more trellis steps of every frame from
+        cursor `first_step`, metrics [F][N] updated in place, decision rows [first_step, first_step + n_steps) written.
+        `symbols` holds each frame's chunk [n_steps][R] -- either a [F][n_steps][R] tensor, or any tensor whose element
+        `f * symbol_frame_stride` starts frame f's chunk (e.g. a view into the whole [F][S][R] batch).  returns renorm_sum [F]
+        for THIS call."""
+        t = self.torch
+        frames = metrics.shape[0]
+        if n_steps is None:
+            n_steps = symbols.shape[1]
+        want = t.int16 if self.soft_bytes == 2 else t.int8
+        if symbols.dtype != want or not symbols.is_cuda:
+            raise ValueError(f"symbols must be a {want} CUDA tensor")
+        if symbol_frame_stride == 0 and not symbols.is_contiguous():
+            raise ValueError("packed chunks must be contiguous (or pass symbol_frame_stride)")
+        ws = self._workspace(frames, L, workspace)
+        rs = t.empty(frames, dtype=t.int64, device=self.device) if renorm_out is None else renorm_out
+        _lib.check(_lib.load().vit_hip_update_batch_resume(
+            self._handle._h, C.c_void_p(symbols.data_ptr()), symbol_frame_stride, frames, first_step, n_steps, L,
+            C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(), C.c_void_p(metrics.data_ptr()),
+            C.c_void_p(rs.data_ptr()), self._stream()))
+        return rs
+
     def chainback(self, frames: int, L: int, end_state=None, out=None, workspace=None):
         t = self.torch
         ws = self._workspace(frames, L, workspace)
@@ -334,6 +371,31 @@ class BatchDecoder:
                                                         C.c_void_p(d_idx.data_ptr()), mask.size, frames,
                                                         C.c_void_p(out.data_ptr()), self._stream()))
         return out
+
+    def synth(self, frames: int, L: int, ebn0_db, seed: int = 1, first_frame: int = 0, tx_out=None, symbols_out=None):
+        """synthetic AWGN frames of this decoder's code, generated in HBM by one HIP kernel (vit_hip_synth_batch: the
+        reference BER harness's generator, examples/run_snr_ber.cpp:311-359).  ebn0_db=None: noise-free symbols at exactly
+        high / low.  returns (tx_bytes [F][L/8] uint8, symbols [F][L+K-1][R] soft dtype), both on the device."""
+        t = self.torch
+        sdt = t.int16 if self.soft_bytes == 2 else t.int8
+        tx = t.empty((frames, L // 8), dtype=t.uint8, device=self.device) if tx_out is None else tx_out
+        sym = t.empty((frames, L + self.K - 1, self.R), dtype=sdt, device=self.device) if symbols_out is None else symbols_out
+        _lib.check(_lib.load().vit_hip_synth_batch(self._handle._h, frames, L, int(seed), int(first_frame),
+                                                   0.0 if ebn0_db is None else float(ebn0_db), 1 if ebn0_db is None else 0,
+                                                   C.c_void_p(tx.data_ptr()), C.c_void_p(sym.data_ptr()), self._stream()))
+        return tx, sym
+
+    def count_bit_errors(self, a, b, count=None):
+        """number of differing bits between two device byte tensors (get_total_bit_errors, test_helpers.h:95-104), added to
+        the one-element int64 device tensor `count` (created zeroed when None); no host synchronisation."""
+        t = self.torch
+        if a.dtype != t.uint8 or b.dtype != t.uint8 or a.numel() != b.numel() or not (a.is_contiguous() and b.is_contiguous()):
+            raise ValueError("need two contiguous uint8 tensors of equal size")
+        if count is None:
+            count = t.zeros(1, dtype=t.int64, device=self.device)
+        _lib.check(_lib.load().vit_hip_count_bit_errors(self._handle._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                                        a.numel(), C.c_void_p(count.data_ptr()), self._stream()))
+        return count
 
     def export_decisions(self, frames: int, L: int, n_steps: int = None, workspace=None):
         """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words).  Every

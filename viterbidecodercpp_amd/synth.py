@@ -106,3 +106,70 @@ def make_frames_torch(code, cfg, frames: int, L: int, ebn0_db, seed: int = 1, de
                 v = torch.sign(v) * torch.floor(torch.abs(v) + 0.5)
                 sym[f0:f1, :, i] = torch.clamp(v, low, high).to(tdtype)
     return tx, sym
+
+
+# ---- host mirror of the device generator (csrc/kernels_synth.hpp: vit_hip_synth_batch) -------------------------------------
+# Same counter-based construction, so a test can regenerate any frame of a device batch: info bytes and noise-free symbols
+# exactly; noisy symbols up to the last-ulp differences between the device's and numpy's float32 log / sin / cos.
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on numpy uint32 arrays (broadcast); returns the 4 output words."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & M32, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & M32
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def philox_info_bytes(frames: int, n_bytes: int, seed: int, first_frame: int = 0) -> np.ndarray:
+    """info byte i of frame f = byte (i & 15) of Philox(ctr = {i >> 4, f_lo, 0, f_hi}, key = seed)."""
+    f = (np.arange(frames, dtype=np.uint64) + np.uint64(first_frame))[:, None]
+    blk = np.arange((n_bytes + 15) // 16, dtype=np.uint64)[None, :]
+    x = philox4x32_10(blk, f & np.uint64(0xFFFFFFFF), 0, f >> np.uint64(32), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = np.stack(x, axis=-1)                                 # [F][blocks][4] little-endian words
+    return np.ascontiguousarray(words).view(np.uint8).reshape(frames, -1)[:, :n_bytes].copy()
+
+
+def philox_normals(frames: int, n: int, seed: int, first_frame: int = 0) -> np.ndarray:
+    """deviate j of frame f: Box-Muller on Philox(ctr = {j >> 2, f_lo, 1, f_hi}); float32 [F][n]."""
+    f = (np.arange(frames, dtype=np.uint64) + np.uint64(first_frame))[:, None]
+    blk = np.arange((n + 3) // 4, dtype=np.uint64)[None, :]
+    x = philox4x32_10(blk, f & np.uint64(0xFFFFFFFF), 1, f >> np.uint64(32), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    two24 = np.float32(5.9604644775390625e-08)
+    z = []
+    for h in range(2):
+        u1 = ((x[2 * h] >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * two24
+        u2 = (x[2 * h + 1] >> np.uint32(8)).astype(np.float32) * two24
+        r = np.sqrt(np.float32(-2.0) * np.log(u1)).astype(np.float32)
+        ang = (np.float32(2.0) * u2).astype(np.float64) * np.pi   # sincospi(2 u2): exact argument, then one rounding
+        z.append((r * np.cos(ang).astype(np.float32)).astype(np.float32))
+        z.append((r * np.sin(ang).astype(np.float32)).astype(np.float32))
+    return np.stack(z, axis=-1).reshape(frames, -1)[:, :n]
+
+
+def make_frames_philox_numpy(code, cfg, frames: int, L: int, ebn0_db, seed: int = 1, first_frame: int = 0):
+    """numpy mirror of BatchDecoder.synth / vit_hip_synth_batch: (tx_bytes [F][L/8], symbols [F][S][R])."""
+    assert L % 8 == 0
+    K, R = code.K, code.R
+    S = L + K - 1
+    tx = philox_info_bytes(frames, L // 8, seed, first_frame)
+    coded = encode_bits_numpy(K, R, code.G, tx)
+    high, low = cfg.soft_decision_high, cfg.soft_decision_low
+    if ebn0_db is None:
+        return tx, np.where(coded != 0, high, low).astype(cfg.soft_dtype)
+    f32 = np.float32
+    esn0 = f32(ebn0_db) - f32(10.0) * np.log10(f32(R)).astype(f32)
+    var = np.power(f32(10.0), -(esn0 + f32(3.0)) / f32(10.0)).astype(f32)
+    sigma = np.sqrt(var).astype(f32)
+    mean = (f32(high) + f32(low)) / f32(2.0)
+    scale = ((f32(high) - f32(low)) / f32(2.0)) * (f32(1.0) / np.sqrt(f32(1.0) + var).astype(f32))
+    z = philox_normals(frames, S * R, seed, first_frame).reshape(frames, S, R)
+    noisy = (np.where(coded != 0, f32(1.0), f32(-1.0)).astype(f32) + (sigma * z).astype(f32)).astype(f32)
+    v = ((noisy * scale).astype(f32) + mean).astype(f32)
+    q = _round_half_away(v)
+    return tx, np.clip(q, low, high).astype(cfg.soft_dtype)
