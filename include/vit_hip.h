@@ -79,6 +79,10 @@ typedef struct vit_hip_info {
     int32_t soft_decision_high, soft_decision_low; /* recovered from the branch table */
     uint32_t polynomials[16];                      /* recovered G[i] (bit 0 and bit K-1 forced to 1), 0 if not linear */
     int32_t table_is_linear;
+    int32_t workspace_tile_frames; /* the decision workspace is an array of independent slabs of this many frames: frame f
+                                      lives in slab f / tile, which starts vit_hip_workspace_bytes(h, tile, L) * (f / tile)
+                                      bytes into the workspace -- a slab-aligned sub-range of a batch can be chained back or
+                                      exported on its own by passing that address */
 } vit_hip_info;
 
 const char* vit_hip_last_error(void);

@@ -31,6 +31,7 @@ public:
 
     const soft_t* operator[](size_t rate_index) const { return m_rows[rate_index].data(); }
     const soft_t* data() const { return m_rows[0].data(); }   // [R][NUMSTATES], rows contiguous
+    soft_t* data() { return m_rows[0].data(); }               // writable: the receiving side of vit_hip_broadcast_table
     soft_t soft_decision_high() const { return m_high; }
     soft_t soft_decision_low() const { return m_low; }
 

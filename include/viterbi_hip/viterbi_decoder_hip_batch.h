@@ -60,6 +60,36 @@ public:
         check(vit_hip_depuncture_batch(m_hip, d_punctured, punctured_per_frame, d_source_index, symbols_per_frame(total_bits),
                                        frames, d_symbols_out, stream), "vit_hip_depuncture_batch");
     }
+    // batched streaming: decoders that keep their state on the device between calls (the reference's update() cursor,
+    // viterbi_decoder_scalar.h:37-54): reset() once, then resume() over consecutive step ranges, then chainback()
+    void reset(size_t frames, error_t* d_metrics, const uint32_t* d_start_state = nullptr, void* stream = nullptr) {
+        check(vit_hip_reset_batch(m_hip, frames, d_start_state, d_metrics, stream), "vit_hip_reset_batch");
+    }
+    void resume(const soft_t* d_symbols, size_t symbol_frame_stride, size_t frames, size_t first_step, size_t n_steps,
+                size_t total_bits, void* d_workspace, size_t workspace_size, error_t* d_metrics_inout,
+                uint64_t* d_renorm_sum = nullptr, void* stream = nullptr) {
+        check(vit_hip_update_batch_resume(m_hip, d_symbols, symbol_frame_stride, frames, first_step, n_steps, total_bits,
+                                          d_workspace, workspace_size, d_metrics_inout, d_renorm_sum, stream),
+              "vit_hip_update_batch_resume");
+    }
+    // test / measurement harness on the device: the BER harness's frame generator (examples/run_snr_ber.cpp:311-359) and
+    // get_total_bit_errors (examples/helpers/test_helpers.h:95-104)
+    void synth(size_t frames, size_t total_bits, uint64_t seed, uint64_t first_frame, float ebn0_db, bool noise_free,
+               uint8_t* d_tx_bytes, soft_t* d_symbols, void* stream = nullptr) {
+        check(vit_hip_synth_batch(m_hip, frames, total_bits, seed, first_frame, ebn0_db, noise_free ? 1 : 0, d_tx_bytes,
+                                  d_symbols, stream), "vit_hip_synth_batch");
+    }
+    void count_bit_errors(const uint8_t* d_a, const uint8_t* d_b, size_t n_bytes, uint64_t* d_count, void* stream = nullptr) {
+        check(vit_hip_count_bit_errors(m_hip, d_a, d_b, n_bytes, d_count, stream), "vit_hip_count_bit_errors");
+    }
+    // multi-GPU set-up: the shared branch table and config travel once from rank `root` to every rank of an RCCL
+    // communicator (ncclComm_t); each rank then constructs its own decoder from its copy.  The other ranks pass a table
+    // built from any polynomials (it is overwritten) -- the reference shares one table between decoders (README.md:14)
+    static void broadcast_table(void* nccl_comm, int root, int rank, BranchTable& table, Config& config, int device,
+                                void* stream = nullptr) {
+        check(vit_hip_broadcast_table(nccl_comm, root, rank, int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)),
+                                      table.data(), &config, device, stream), "vit_hip_broadcast_table");
+    }
     vit_hip_handle hip_handle() const { return m_hip; }
 
 private:

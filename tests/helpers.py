@@ -9,6 +9,19 @@ DECODE_TYPES = ["SOFT16", "SOFT8", "HARD8"]
 _DT_ID = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}
 
 
+def decisions_match_fixture(got, g):
+    """decision words [S][W] against a golden fixture: the words themselves, or -- for the fixtures whose history is stored
+    as hashes (tests/golden/make_golden.py: HASHED) -- the SHA-256 prefix of every row plus the SHA-256 of the whole."""
+    import hashlib
+
+    got = np.ascontiguousarray(got, dtype=np.uint64)
+    if "decisions" in g.files:
+        return np.array_equal(got, g["decisions"])
+    rows = np.asarray([np.frombuffer(hashlib.sha256(r.tobytes()).digest()[:8], dtype=np.uint64)[0] for r in got], dtype=np.uint64)
+    whole = np.frombuffer(hashlib.sha256(got.tobytes()).digest(), dtype=np.uint8)
+    return np.array_equal(rows, g["decision_row_sha256_8"]) and np.array_equal(whole, g["decisions_sha256"])
+
+
 def oracle_cfg(decode_type, R):
     return pyoracle.stock_config(_DT_ID[decode_type], R)
 

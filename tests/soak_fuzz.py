@@ -1,51 +1,68 @@
 #!/usr/bin/env python3
 """Randomised soak on the GPU box: tests/test_gpu_fuzz.py's comparison (decision words, metrics, renormalisation sums,
-chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  usage: python tests/soak_fuzz.py [seconds] [first_seed]"""
-import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import numpy as np
-import torch
-from oracle import pyoracle
-from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib
-from tests.test_gpu_fuzz import random_config
+chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  Every third case also feeds the decoders in
+two chunks through the resumed update (vit_hip_update_batch_resume) and must land on the same results.
+    python tests/soak_fuzz.py [seconds] [first_seed]        (tests/test_gpu_soak.py runs a 45-second slice under pytest)"""
+import os
+import sys
+import time
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-pyoracle.ensure_built()
-oracle = pyoracle.Oracle()
-CASES = [(COMMON_CODES[2], [_lib.PLAN_REG]), (COMMON_CODES[3], [_lib.PLAN_REG]), (COMMON_CODES[4], [_lib.PLAN_REG]),
-         (COMMON_CODES[5], [_lib.PLAN_REG]), (COMMON_CODES[6], [_lib.PLAN_REG]), (COMMON_CODES[0], [_lib.PLAN_REG]),
-         (COMMON_CODES[1], [_lib.PLAN_REG]), (Code("K11", 11, 2, (0o3345, 0o3613)), [_lib.PLAN_LDS2]),
-         (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), [_lib.PLAN_LDS2]), (COMMON_CODES[7], [_lib.PLAN_LDS2])]
-t_end = time.time() + budget
-n = 0
-while time.time() < t_end:
-    for ci, (code, plans) in enumerate(CASES):
-        for width in (2, 1):
-            rng = np.random.default_rng(100000 * seed + 10 * ci + width)
-            trial = int(rng.integers(0, 4))
-            cfg = random_config(rng, width, trial)
-            sdt = np.int16 if width == 2 else np.int8
-            table = ViterbiBranchTable(code.K, code.R, code.G, cfg.high, cfg.low, sdt)
-            config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
-                                           cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
-            F = int(rng.integers(1, 70)) if code.K < 11 else int(rng.integers(1, 5))
-            L = int(rng.integers(1, 200)) if code.K < 11 else (int(rng.integers(1, 60)) if code.K < 15 else int(rng.integers(1, 24)))
-            S = L + code.K - 1
-            lim = 1 << (8 * width - 1)
-            if rng.integers(0, 2):
-                sym = rng.integers(cfg.low, cfg.high + 1, size=(F, S, code.R)).astype(sdt)
-            else:
-                sym = rng.integers(-lim, lim, size=(F, S, code.R)).astype(sdt)
-            N = code.num_states
-            ss = rng.integers(0, N, F).astype(np.int32)
-            es = rng.integers(0, N, F).astype(np.int32)
-            want = [oracle.decode(code.K, code.R, code.G, cfg, sym[f], L, start_state=int(ss[f]), end_state=int(es[f])) for f in range(F)]
-            d_sym = torch.from_numpy(sym).cuda()
-            for plan in plans:
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
+    """returns the number of (code, width, config) cases checked; raises AssertionError on the first mismatch"""
+    import torch
+    from oracle import pyoracle
+    from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib
+    from tests.test_gpu_fuzz import random_config
+
+    pyoracle.ensure_built()
+    oracle = pyoracle.Oracle()
+    cases = [(COMMON_CODES[2], _lib.PLAN_REG), (COMMON_CODES[3], _lib.PLAN_REG), (COMMON_CODES[4], _lib.PLAN_REG),
+             (COMMON_CODES[5], _lib.PLAN_REG), (COMMON_CODES[6], _lib.PLAN_REG), (COMMON_CODES[0], _lib.PLAN_REG),
+             (COMMON_CODES[1], _lib.PLAN_REG), (Code("K11", 11, 2, (0o3345, 0o3613)), _lib.PLAN_LDS2),
+             (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), _lib.PLAN_LDS2), (COMMON_CODES[7], _lib.PLAN_LDS2),
+             (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS)]
+    t_end = time.time() + budget_seconds
+    seed, n = first_seed, 0
+    while time.time() < t_end:
+        for ci, (code, plan) in enumerate(cases):
+            for width in (2, 1):
+                rng = np.random.default_rng(100000 * seed + 10 * ci + width)
+                trial = int(rng.integers(0, 4))
+                cfg = random_config(rng, width, trial)
+                sdt = np.int16 if width == 2 else np.int8
+                table = ViterbiBranchTable(code.K, code.R, code.G, cfg.high, cfg.low, sdt)
+                config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
+                                               cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
+                F = int(rng.integers(1, 70)) if code.K < 11 else int(rng.integers(1, 5))
+                L = int(rng.integers(1, 200)) if code.K < 11 else (int(rng.integers(1, 60)) if code.K < 15 else int(rng.integers(1, 24)))
+                S = L + code.K - 1
+                lim = 1 << (8 * width - 1)
+                if rng.integers(0, 2):
+                    sym = rng.integers(cfg.low, cfg.high + 1, size=(F, S, code.R)).astype(sdt)
+                else:
+                    sym = rng.integers(-lim, lim, size=(F, S, code.R)).astype(sdt)
+                N = code.num_states
+                ss = rng.integers(0, N, F).astype(np.int32)
+                es = rng.integers(0, N, F).astype(np.int32)
+                want = [oracle.decode(code.K, code.R, code.G, cfg, sym[f], L, start_state=int(ss[f]), end_state=int(es[f]))
+                        for f in range(F)]
+                d_sym = torch.from_numpy(sym).cuda()
                 dec = BatchDecoder(table, config, plan=plan)
-                met, rs = dec.update(d_sym, L, start_state=ss)
+                if n % 3 == 2:          # streamed: two chunks through the resumed update
+                    cut = int(rng.integers(1, S)) if S > 1 else 1
+                    met = dec.reset_batch(F, start_state=ss)
+                    rs = dec.update_resume(d_sym[:, :cut].contiguous(), L, 0, met)
+                    if cut < S:
+                        rs = rs + dec.update_resume(d_sym.reshape(-1)[cut * code.R:], L, cut, met, n_steps=S - cut,
+                                                    symbol_frame_stride=S * code.R)
+                else:
+                    met, rs = dec.update(d_sym, L, start_state=ss)
                 got_dec = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
                 out = dec.chainback(F, L, end_state=es).cpu().numpy()
                 met = met.cpu().numpy()
@@ -56,8 +73,15 @@ while time.time() < t_end:
                     assert np.array_equal(met[f].astype(np.uint32), want[f]["metrics"]), ("metrics", tag)
                     assert int(rs[f].item()) == want[f]["renorm_sum"], ("renorm", tag)
                     assert np.array_equal(out[f], want[f]["bytes"]), ("bytes", tag)
-            n += 1
-    seed += 1
-    if seed % 200 == 0:
-        print(f"  ... {n} cases, seed {seed}", flush=True)
-print(f"soak ok: {n} random (code, width, config) cases, last seed {seed - 1}")
+                n += 1
+        seed += 1
+        if progress and seed % 200 == 0:
+            progress(f"  ... {n} cases, seed {seed}")
+    return n
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    total = soak(budget, seed0, progress=lambda m: print(m, flush=True))
+    print(f"soak ok: {total} random (code, width, config) cases from seed {seed0}")

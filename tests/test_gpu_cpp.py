@@ -11,7 +11,7 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 
 
 def _ensure_built():
-    if not all(os.path.exists(os.path.join(CPP, n)) for n in ("run_simple_hip", "run_tests_hip", "run_batch_hip")):
+    if not all(os.path.exists(os.path.join(CPP, n)) for n in ("run_simple_hip", "run_tests_hip", "run_batch_hip", "run_multi_gpu_hip")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
         subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
 
@@ -22,6 +22,7 @@ def test_cpp_programs_build():
     assert os.access(os.path.join(CPP, "run_simple_hip"), os.X_OK)
     assert os.access(os.path.join(CPP, "run_tests_hip"), os.X_OK)
     assert os.access(os.path.join(CPP, "run_batch_hip"), os.X_OK)
+    assert os.access(os.path.join(CPP, "run_multi_gpu_hip"), os.X_OK)
 
 
 @pytest.mark.gpu
@@ -49,3 +50,14 @@ def test_run_batch_hip():
     p = subprocess.run([os.path.join(CPP, "run_batch_hip")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "mismatching frames=0" in p.stdout and p.stdout.strip().endswith("PASS")
+
+
+@pytest.mark.gpu
+def test_run_multi_gpu_hip():
+    """C++ host, no Python: RCCL communicator over every visible GPU, vit_hip_broadcast_table, one decoder and one shard of
+    the global batch per GPU (one rank on the one-GPU box; the same binary uses all eight on a full node)."""
+    _ensure_built()
+    p = subprocess.run([os.path.join(CPP, "run_multi_gpu_hip"), "4096", "2048"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "table ok" in p.stdout and "BAD" not in p.stdout and p.stdout.strip().endswith("PASS")

@@ -31,7 +31,7 @@ class VitHipInfo(C.Structure):
     _fields_ = [("K", C.c_int32), ("R", C.c_int32), ("soft_bytes", C.c_int32), ("error_bytes", C.c_int32),
                 ("num_states", C.c_int32), ("decision_words", C.c_int32), ("device", C.c_int32), ("plan", C.c_int32),
                 ("soft_decision_high", C.c_int32), ("soft_decision_low", C.c_int32), ("polynomials", C.c_uint32 * 16),
-                ("table_is_linear", C.c_int32)]
+                ("table_is_linear", C.c_int32), ("workspace_tile_frames", C.c_int32)]
 
 
 class VitHipError(RuntimeError):

@@ -373,6 +373,7 @@ int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
     info->soft_decision_high = h->high; info->soft_decision_low = h->low;
     for (int i = 0; i < h->R && i < 16; ++i) info->polynomials[i] = h->linear ? h->G[i] : 0u;
     info->table_is_linear = h->linear ? 1 : 0;
+    info->workspace_tile_frames = h->plan == VIT_HIP_PLAN_REG ? h->reg_code.tile : h->plan == VIT_HIP_PLAN_LDS2 ? 2 : 1;
     return VIT_HIP_OK;
 }
 

@@ -397,12 +397,19 @@ class BatchDecoder:
                                                         a.numel(), C.c_void_p(count.data_ptr()), self._stream()))
         return count
 
-    def export_decisions(self, frames: int, L: int, n_steps: int = None, workspace=None):
-        """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words).  Every
-        plan's workspace is frame-major in units that do not depend on the batch size, so the first `frames` frames of a
-        larger batch's workspace can be exported on their own."""
+    def export_decisions(self, frames: int, L: int, n_steps: int = None, workspace=None, first_frame: int = 0):
+        """decision history in the reference layout: int64 tensor [F][n_steps][W] (bit pattern of uint64 words).  The
+        workspace is an array of independent slabs of `workspace_tile_frames` frames (vit_hip_info), so `frames` frames
+        starting at a slab-aligned `first_frame` of a larger batch can be exported on their own."""
         t = self.torch
         n_steps = (L + self.K - 1) if n_steps is None else n_steps
+        if first_frame:
+            self._handle.refresh()
+            tile = self._handle.info.workspace_tile_frames
+            if first_frame % tile:
+                raise ValueError(f"first_frame must be a multiple of {tile} for this plan")
+            base = self._ws if workspace is None else workspace
+            workspace = base[(first_frame // tile) * self.workspace_bytes(tile, L):]
         ws = self._workspace(frames, L, workspace)
         dec = t.empty((frames, n_steps, self.W), dtype=t.int64, device=self.device)
         _lib.check(_lib.load().vit_hip_export_decisions(self._handle._h, C.c_void_p(ws.data_ptr()), frames, n_steps, L,
