@@ -33,7 +33,7 @@ def short(name):
 
 
 lines = [f"# rocprofv3 summary `{tag}`", "",
-         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline`",
+         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline " + " ".join(sys.argv[3:]) + "`",
          "(scripts/profile.sh; the 2 warm-up launches are included in the averages).", ""]
 
 # ---- pass 1: kernel stats ----
@@ -95,6 +95,10 @@ for k in sorted(counters):
     if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
         lines.append(f"VALU instructions per wave = {c['SQ_INSTS_VALU']/c['SQ_WAVES']:.0f}; "
                      f"SALU per wave = {c.get('SQ_INSTS_SALU', 0)/c['SQ_WAVES']:.0f}")
+    if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+        lines.append(f"SQ_WAIT_ANY / SQ_WAVE_CYCLES = {c['SQ_WAIT_ANY']/c['SQ_WAVE_CYCLES']:.1%}; "
+                     f"SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {c.get('SQ_ACTIVE_INST_VALU', 0)/c['SQ_WAVE_CYCLES']:.1%}; "
+                     f"SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {c.get('SQ_WAIT_INST_ANY', 0)/c['SQ_WAVE_CYCLES']:.1%}")
     if "SQ_LDS_BANK_CONFLICT" in c:
         act = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
         lines.append(f"LDS bank-conflict cycles / LDS active cycles = {c['SQ_LDS_BANK_CONFLICT']:.6g} / {act:.6g}"
@@ -113,8 +117,14 @@ if key and traffic:
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
     upd = [k for k in traffic if "update_kernel" in k]
     cb = [k for k in traffic if "chainback_kernel" in k]
+    def valu(k):
+        v = counters[k].get("SQ_INSTS_VALU")
+        return sum(v) / len(v) if v else None
+
     tj[key] = {"source": f"profiles/{tag}_summary.md",
                "update_kernel_hbm_bytes_per_launch": traffic[upd[0]]["total"] if upd else None,
                "chainback_kernel_hbm_bytes_per_launch": traffic[cb[0]]["total"] if cb else None,
+               "update_kernel_valu_insts_per_launch": valu(upd[0]) if upd else None,
+               "chainback_kernel_valu_insts_per_launch": valu(cb[0]) if cb else None,
                "detail": traffic}
     json.dump(tj, open(tpath, "w"), indent=1)

@@ -82,12 +82,22 @@ __global__ void lds_update_kernel(LdsUpdateArgs a) {
     __syncthreads();
 
     // ---- symbol window: 2 x 64 dwords of this frame's stream, one dword per lane ----
+    // The window is aligned on the ABSOLUTE address (the caller's pointer need only be soft_t aligned), and a dword that
+    // straddles the end of the buffer is assembled from single bytes: nothing outside [symbols, symbols + total) is read.
     const size_t frame_b = f * a.sym_frame_stride_bytes;
-    size_t wbase = frame_b & ~(size_t)3;
-    int ob = (int)(frame_b & 3);   // byte offset of the current step inside the window
+    const size_t base_mis = (size_t)((uintptr_t)a.symbols & 3u);
+    size_t wbase = (frame_b + base_mis) & ~(size_t)3;          // offset from the dword-aligned address below `symbols`
+    int ob = (int)((frame_b + base_mis) & 3);   // byte offset of the current step inside the window
+    const uint8_t* const sym_al = a.symbols - base_mis;         // dword aligned; bytes [0, base_mis) are not ours
+    const size_t end_al = a.sym_total_bytes + base_mis;
     auto load_win = [&](size_t base) -> uint32_t {
         const size_t addr = base + 4 * (size_t)lane;
-        return addr < a.sym_total_bytes ? *(const uint32_t*)(a.symbols + addr) : 0u;
+        if (addr >= base_mis && addr + 4 <= end_al) return *(const uint32_t*)(sym_al + addr);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (addr + k >= base_mis && addr + k < end_al) v |= (uint32_t)sym_al[addr + k] << (8 * k);
+        return v;
     };
     uint32_t win0 = load_win(wbase), win1 = load_win(wbase + 256);
 
