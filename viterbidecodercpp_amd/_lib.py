@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvit_hip.so")
+# VIT_HIP_LIB_PATH: load another build of the same library (A/B timing of kernel variants; never set in tests or bench)
+LIB_PATH = os.environ.get("VIT_HIP_LIB_PATH") or os.path.join(_HERE, "libvit_hip.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NO_DEVICE, ERR_WORKSPACE = -1, -2, -3, -4, -5

@@ -30,6 +30,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -57,6 +59,7 @@ VIT_L2 u32 l2_and_or(u32 a, u32 mask, u32 c) {
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
     return d;
 }
+VIT_L2 void l2_opaque(u32& x) { asm volatile("" : "+v"(x)); }   // the compiler may not assume anything about x across this point
 template <class F, int... Is>
 VIT_L2 void l2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -111,25 +114,44 @@ __host__ __device__ constexpr u32 lds2_sw(u32 s, u32 n) {
 
 template <int K>
 struct Lds2Geom {
-    static constexpr int SBITS = K - 1, N = 1 << SBITS, H = N / 2, T = N / 16, NW = T / 64;
-    static constexpr int BLK = 4;                          // trellis steps per barrier
+    static constexpr int SBITS = K - 1, N = 1 << SBITS, H = N / 2;
+    static constexpr int G = N / 16;                       // radix-16 groups (= decision dwords per trellis step and frame pair)
+    static constexpr int JB = SBITS - 4;                   // bits of a group index
+    static constexpr int GPT = G >= 256 ? 2 : 1;           // groups per thread (K >= 13: two, A = tid and B = tid + T)
+    static constexpr int T = G / GPT, NW = T / 64;
+    static constexpr int BLK = 4;                          // trellis steps per block
     static constexpr int CPW = (BLK + NW - 1) / NW;        // tables a wavefront builds per block
-    static constexpr size_t smem_bytes = (size_t)2 * N * 4 + (size_t)2 * BLK * 64 * 8 + 32 * 4;
+    // K = 15: 512 threads and 72 KiB of LDS per workgroup, so that TWO workgroups share a CU (4 waves per SIMD, 128 VGPRs)
+    static constexpr int MINW = K == 15 ? 4 : 2;
+    static constexpr size_t tab_bytes = (size_t)2 * BLK * GPT * 64 * 8;
+    static constexpr size_t smem_bytes = tab_bytes + 32 * 4 + (size_t)N * 4;
     static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..15");
 };
 
+// One workgroup per frame pair.  The N packed metrics live in ONE LDS buffer that a block of four trellis steps updates IN
+// PLACE: every thread loads the 16 states of each of its radix-16 groups, all threads pass barrier B1 (nobody reads the old
+// values after it), four stages run in registers, the 16 new states of each group are stored, barrier B2.  Half the LDS of
+// a double-buffered block, so that two workgroups fit a CU and one computes while the other waits at its barriers (the
+// one-workgroup-per-CU build spent 16 % of its time in the barrier: 58.0 ms with, 49.0 ms without, 4096 x 8192 at K = 15).
+// In place means a block cannot be re-run: the rare mid-block renormalisation (state 0 reaching the threshold after one of
+// the first three steps) is therefore PREDICTED, not discovered -- new[0] <= old[0] + E[pattern 0], so thread 0 bounds
+// metric[0] over the next block's first three steps from that block's (already built) tables and, if the bound reaches the
+// threshold, the whole workgroup takes the careful stage-by-stage routine for that block.
 template <int K, int SHIFT>
-__global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateArgs a) {
+__global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update_kernel(Lds2UpdateArgs a) {
     using GM = Lds2Geom<K>;
-    constexpr int N = GM::N, T = GM::T, NW = GM::NW, BLK = GM::BLK, CPW = GM::CPW, SBITS = GM::SBITS;
+    constexpr int N = GM::N, T = GM::T, G = GM::G, GPT = GM::GPT, NW = GM::NW, BLK = GM::BLK, SBITS = GM::SBITS;
     constexpr u32 BIAS2 = 0x80008000u;
+    constexpr u32 STEP_TAB = (u32)GPT * 512u;              // bytes of one step's tables (group-A table, group-B table)
+    constexpr u32 SET_TAB = (u32)BLK * STEP_TAB;           // bytes of one table set (the four steps of a block)
     extern __shared__ __attribute__((aligned(16))) u32 lds2_smem[];
-    // tables first: their byte offsets (< 4 KiB) fit instruction offsets and 16-bit halves of a register
-    uint2* const etab = (uint2*)lds2_smem;                     // [2][BLK][64] {E, max_error - E}
-    u32* const wmin = (u32*)(etab + 2 * BLK * 64);             // [16]
-    u32* const flag = wmin + 16;                               // [2] mid-block renormalisation seen by thread 0; [2] scratch
+    // tables first: their byte offsets (< 8 KiB) fit instruction offsets and 16-bit halves of a register
+    uint2* const etab = (uint2*)lds2_smem;                     // [2 sets][BLK][GPT][64] {E, max_error - E}
+    u32* const wmin = (u32*)((char*)lds2_smem + GM::tab_bytes); // [16]
+    u32* const flag = wmin + 16;                               // [0] careful routine wanted for the next block; [2] scratch; [4] arrivals
+    u32* const arrive = flag + 4;                              // wavefronts that have loaded their block's metrics, running total
     uint64_t* const rs_acc = (uint64_t*)(flag + 8);            // [2] sum of subtracted minima, frame A / B (thread 0 only)
-    u32* const met = flag + 16;                                // [2][N], 16-byte aligned
+    u32* const met = flag + 16;                                // [N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 pair = blockIdx.x;
@@ -143,9 +165,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
     const u32 THRM1B2 = ((u32)(uint16_t)(a.cfg.threshold - 1) * 0x10001u) ^ BIAS2;   // metric >= thr  <=>  biased > this
     const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
 
-    // ---- loop-invariant per-thread constants: table byte offset of the branch pattern of each of my 4 x 8 butterflies ----
-    // (two 16-bit LDS byte offsets per register: 16 registers instead of 32 keep the kernel inside the 128 VGPRs that
-    // 1024-thread workgroups get; unpacking costs one 2.5-cycle and/shift per table read)
+    // ---- loop-invariant per-thread constants: table byte offset of the branch pattern of each of my 4 x 8 group-A
+    // butterflies (two 16-bit LDS byte offsets per register).  Group B = group A + T differs in ONE bit of the butterfly
+    // index, and the code is linear (lds2_supported()), so its pattern is the group-A pattern ^ pattern[that bit]: the
+    // builder writes a second table per step with the entries permuted by that XOR, and group B reads it through the same
+    // offsets (+512: an instruction offset).
     u32 prow2[BLK][4];
     l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
@@ -156,8 +180,8 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
                 constexpr int h = 2 * h2 + decltype(ec)::value;
                 constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
                 const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
-                // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + BLK*512, an instruction offset)
-                const u32 off = (u32)(C * 512) + ((u32)a.pattern[lower] & 63u) * 8u;
+                // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + SET_TAB, an instruction offset)
+                const u32 off = (u32)C * STEP_TAB + ((u32)a.pattern[lower] & 63u) * 8u;
                 pk |= off << (16 * decltype(ec)::value);
             });
             prow2[C][h2] = pk;
@@ -177,7 +201,6 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             }
             met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
         }
-        if (tid < 16) flag[tid] = 0;
     } else {
         const u32 sA = a.start_state ? (a.start_state[fA] & (u32)(N - 1)) : 0u;
         const u32 sB = a.start_state ? (a.start_state[fB] & (u32)(N - 1)) : 0u;
@@ -186,10 +209,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             const u32 hi = ((u32)s == sB) ? a.cfg.init_start : a.cfg.init_non_start;
             met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
         }
-        if (tid < 16) flag[tid] = 0;          // flags and the two 64-bit renormalisation sums
     }
+    if (tid < 16) flag[tid] = 0;              // flags and the two 64-bit renormalisation sums
 
-    // ---- branch-metric table builder: lane p makes entry p of the table of one step ----
+    // ---- branch-metric table builder: lane p makes entry p of the tables of one step ----
     const uint8_t* symA = a.symbols + (size_t)fA * a.sym_frame_stride_bytes;
     const uint8_t* symB = a.symbols + (size_t)fB * a.sym_frame_stride_bytes;
     auto load_syms = [&](u32 abs_step, u32 (&y)[6]) __attribute__((always_inline)) {
@@ -210,20 +233,30 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             }
         }
     };
-    auto build_table = [&](uint2* tab, const u32 (&y)[6]) __attribute__((always_inline)) {
+    // pattern of the butterfly-index bit that separates group B from group A in stage c: bit JB-1+c
+    u32 xorB[BLK] = {0, 0, 0, 0};
+    if constexpr (GPT == 2) {
+#pragma unroll
+        for (int c = 0; c < BLK; ++c) xorB[c] = (u32)a.pattern[(size_t)1 << (GM::JB - 1 + c)] & 63u;
+    }
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb) __attribute__((always_inline)) {
         // E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107)
-        u32 e = 0;
+        u32 e = 0, eb = 0;
+        const u32 pb = (u32)lane ^ xb;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
-                const u32 bt = ((lane >> i) & 1) ? HIGH2 : LOW2;
-                const u32 d = l2_sub(bt, y[i]);
-                e = l2_add(e, l2_max_s(d, l2_sub(0u, d)));   // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71)
+                const u32 d1 = l2_sub(HIGH2, y[i]), d0 = l2_sub(LOW2, y[i]);
+                const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));   // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71)
+                e = l2_add(e, ((lane >> i) & 1) ? a1 : a0);
+                eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
             }
         }
         tab[lane] = make_uint2(e, l2_sub(MAXE2, e));
+        if constexpr (GPT == 2) tab[64 + lane] = make_uint2(eb, l2_sub(MAXE2, eb));   // entry p of the group-B table = E[p ^ xb]
     };
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
+    constexpr int CPW = GM::CPW;
     u32 ysym[CPW][6];                        // lds2_supported(): R <= 6
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
@@ -236,24 +269,44 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) load_syms(t0 + (u32)c, ysym[i]);
         }
     };
-    auto tables_build = [&](u32 t0, int buf) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
+    auto tables_build = [&](u32 t0, int set) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) build_table(etab + (buf * BLK + c) * 64, ysym[i]);
+            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin)
+                build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], c == 0 ? xorB[0] : c == 1 ? xorB[1] : c == 2 ? xorB[2] : xorB[3]);
         }
+    };
+    // thread 0: could state 0 reach the threshold after one of the first three steps of the block at t_next, whose tables
+    // are in `set`?  new[0] <= old[0] + E[pattern of butterfly 0 = 0] (wrapping or not), so old[0] + E0 + E1 + E2 bounds it.
+    auto predict = [&](u32 m0_biased, u32 t_next, int set) __attribute__((always_inline)) -> u32 {
+        const u32 m0 = m0_biased ^ BIAS2;
+        u32 lo = m0 & 0xFFFFu, hi = m0 >> 16;
+#pragma unroll
+        for (int c = 0; c < BLK - 1; ++c) {
+            if (t_next + (u32)c < a.t_end) {
+                const u32 e = etab[(size_t)(set * BLK + c) * GPT * 64].x;
+                lo += e & 0xFFFFu;
+                hi += e >> 16;
+            }
+        }
+        const u32 thr = a.cfg.threshold;
+        return (lo >= thr || hi >= thr) ? 1u : 0u;      // threshold 0: always
     };
     const u32 tb0 = a.t_begin & ~(u32)(BLK - 1);   // the block that holds step t_begin (0 for a fresh decode)
     tables_load(tb0);
     tables_build(tb0, 0);
     tables_load(tb0 + BLK);
     __syncthreads();
+    if (tid == 0) flag[0] = predict(met[0], tb0, 0);
+    __syncthreads();
 
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
-    u32 m[16];
-    // one trellis step on the registers: stage C of a block, table `tab`, decisions of step t -> ws  (scalar.h:113-134)
-    auto stage = [&](auto cc, u32 tabset_bytes, u32* wsp) __attribute__((always_inline)) {
+    u32 mA[16], mB[GPT == 2 ? 16 : 1];
+    // one trellis step on the 16 registers of one group: stage C of a block, tables at `tab_off` from the packed offsets,
+    // decisions of the step -> one dword  (scalar.h:113-134)
+    auto stage = [&](auto cc, u32 (&m)[16], u32 tab_off, u32* wdst) __attribute__((always_inline)) {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
         // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
         // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
@@ -263,7 +316,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             constexpr int h = decltype(hc)::value;
             constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
             const u32 off = (h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu);
-            const uint2 ee = *(const uint2*)((const char*)lds2_smem + off + tabset_bytes);
+            const uint2 ee = *(const uint2*)((const char*)lds2_smem + off + tab_off);
             const u32 ma = m[r0], mb = m[r1];
             const u32 x0 = l2_add(ma, ee.x), y0 = l2_add(mb, ee.y);   // -> next state 2a
             const u32 x1 = l2_add(ma, ee.y), y1 = l2_add(mb, ee.x);   // -> next state 2a+1
@@ -275,31 +328,61 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
             // one chain: 1 and + 7 and_or (a second chain would cost a join)
             if constexpr (h == 0) lo4 = sg & 0x01010101u;
             else lo4 = l2_and_or(sg, 0x01010101u << h, lo4);
+            // four butterflies in flight at a time: the temporaries of eight do not fit beside two groups of metrics
+            if constexpr (GPT == 2 && (h & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         });
-        wsp[C * T + tid] = lo4;
+        *wdst = lo4;
     };
-    // swizzled metric buffers (lds2_sw): read view, register r = state r*T + j; write view, piece q = states 16 j + 4 q ...
-    constexpr bool SEP = (T / 16) % 8 == 0;     // r*T/16 does not reach the three bits the swizzle touches: base + r*T/4
-    const u32 rd_base = lds2_sw((u32)tid, (u32)N);
-    auto load_metrics = [&](const u32* src) __attribute__((always_inline)) {
+    auto stage_all = [&](auto cc, int set, u32* wsp) __attribute__((always_inline)) {   // wsp: decision row of block step 0
+        constexpr int C = decltype(cc)::value;
+        stage(cc, mA, (u32)set * SET_TAB, wsp + C * G + tid);
+        if constexpr (GPT == 2) stage(cc, mB, (u32)set * SET_TAB + 512u, wsp + C * G + T + tid);
+    };
+    // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
+    constexpr bool SEP = (G / 16) % 8 == 0;     // r*G/16 does not reach the three bits the swizzle touches: base + r*G/4
+    // Addresses are formed from an OPAQUE copy of the thread index inside every block: left to itself hipcc hoists the 32 + 8
+    // per-register addresses out of the main loop and spills them (236 bytes of scratch, ~50 reloads per block); this way a
+    // group's reads are one base register + instruction offsets and the four store addresses cost one v_xor each.
+    auto load_group = [&](u32 (&m)[16], u32 g) __attribute__((always_inline)) {
+        const u32* const p = met + lds2_sw(g, (u32)N);
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            if constexpr (SEP) m[r] = src[rd_base + r * (T / 4)];
-            else m[r] = src[lds2_sw((u32)(r * T) + (u32)tid, (u32)N)];
+            if constexpr (SEP) m[r] = p[r * (G / 4)];
+            else m[r] = met[lds2_sw((u32)(r * G) + g, (u32)N)];
         });
     };
-    auto store_metrics = [&](u32* dst) __attribute__((always_inline)) {      // after stage 3: register r holds state 16 j + r
+    auto store_group = [&](const u32 (&m)[16], u32 g) __attribute__((always_inline)) {   // after stage 3: register r holds state 16 g + r
         l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
-            *(uint4*)(dst + q * (N / 4) + (((u32)tid ^ (u32)(q << 1)) << 2)) = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+            uint4* const p = (uint4*)(met + q * (N / 4)) + (g ^ (u32)(q << 1));
+            *p = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
         });
+    };
+    auto opaque_tid = [&]() __attribute__((always_inline)) -> u32 {
+        u32 t = (u32)tid;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    auto load_metrics = [&]() __attribute__((always_inline)) {
+        const u32 t = opaque_tid();
+        load_group(mA, t);
+        if constexpr (GPT == 2) load_group(mB, t + (u32)T);
+    };
+    auto store_metrics = [&]() __attribute__((always_inline)) {
+        const u32 t = opaque_tid();
+        store_group(mA, t);
+        if constexpr (GPT == 2) store_group(mB, t + (u32)T);
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
     auto renormalise = [&](u32 need) __attribute__((always_inline)) {
         const u32 msk = ((need & 0x8000u) ? 0x0000FFFFu : 0u) | ((need & 0x80000000u) ? 0xFFFF0000u : 0u);
-        u32 mn = m[0];
+        u32 mn = mA[0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mn = l2_min_s(mn, m[i]);
+        for (int i = 1; i < 16; ++i) mn = l2_min_s(mn, mA[i]);
+        if constexpr (GPT == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mn = l2_min_s(mn, mB[i]);
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));
         if (lane == 0) wmin[wave] = mn;
@@ -307,108 +390,125 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T) lds2_update_kernel(Lds2UpdateA
         for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wmin[w]);
         const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = l2_sub(m[i], sub);
+        for (int i = 0; i < 16; ++i) mA[i] = l2_sub(mA[i], sub);
+        if constexpr (GPT == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mB[i] = l2_sub(mB[i], sub);
+        }
         if (tid == 0) {                       // update()'s return value: kept in LDS, not in four VGPRs of every thread
             rs_acc[0] += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
             rs_acc[1] += (uint64_t)((sub >> 16) >> SHIFT);
         }
         __syncthreads();                      // wmin may be rewritten by the next reduction
     };
-    // the careful version of a block: `nst` stages (1..4) with the threshold test and the reduction after EVERY stage; used
-    // when thread 0 saw state 0 cross the threshold inside a block, and for the last partial block of a frame
-    auto slow_block = [&](u32 t0, int buf, int c_first, int nst, bool build_next) __attribute__((always_inline)) {
-        const u32* src = met + buf * N;
-        u32* dst = met + (buf ^ 1) * N;
-        if (build_next) {                      // entry block of a resumed call: nobody has built the next block's tables yet
-            tables_build(t0 + BLK, buf ^ 1);
-            tables_load(t0 + 2 * BLK);
-        }
-        // an opaque copy of the thread index: the 3 x 16 scatter addresses of the partial-block write-back below are loop
-        // invariant, and hoisted out of the main loop they cost the FAST path its registers (spills) for a once-per-frame use
+    // the careful version of a block: stages [c_first, nst) with the threshold test and the reduction after EVERY stage; used
+    // when the prediction says state 0 may cross the threshold inside the block, for the entry block of a resumed call
+    // (c_first > 0) and for the last partial block of a frame (nst < BLK).  Returns the prediction for the next block.
+    auto slow_block = [&](u32 t0, int set, int c_first, int nst) __attribute__((always_inline)) -> bool {
+        tables_build(t0 + BLK, set ^ 1);       // nobody has built the next block's tables yet
+        tables_load(t0 + 2 * BLK);
+        // an opaque copy of the thread index: the scatter / gather addresses below are loop invariant, and hoisted out of the
+        // main loop they would cost the FAST path its registers for a once-per-frame use
         u32 tid_o = (u32)tid;
         asm volatile("" : "+v"(tid_o));
         if (c_first == 0) {
-            load_metrics(src);
+            load_metrics();
         } else {                               // mid-block entry: the registers as stage c_first - 1 would have left them
             l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
                 constexpr u32 r = decltype(rc)::value;
-                m[r] = src[lds2_sw(lds2_state_of(c_first - 1, r, tid_o, SBITS), (u32)N)];
+                mA[r] = met[lds2_sw(lds2_state_of(c_first - 1, r, tid_o, SBITS), (u32)N)];
+                if constexpr (GPT == 2) mB[r] = met[lds2_sw(lds2_state_of(c_first - 1, r, tid_o + (u32)T, SBITS), (u32)N)];
             });
         }
+        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // keeps the fast path's count in step
+        __syncthreads();                       // B1: all inputs are in registers, the buffer may be overwritten
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
             if (C >= c_first && C < nst) {
-                stage(cc, (u32)(buf * BLK * 512), ws_pair + (size_t)t0 * T);
-                // state 0 is register 0 of thread 0 after every stage
-                if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
+                stage_all(cc, set, ws_pair + (size_t)t0 * G);
+                // state 0 is register 0 of thread 0's first group after every stage
+                if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
                 __syncthreads();
                 const u32 need = flag[2];
                 __syncthreads();
                 if (need != 0) renormalise(need);
                 if (C == nst - 1) {
                     if (C == BLK - 1) {
-                        store_metrics(dst);
+                        store_metrics();
                     } else {
                         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
                             constexpr u32 r = decltype(rc)::value;
-                            dst[lds2_sw(lds2_state_of(C, r, tid_o, SBITS), (u32)N)] = m[r];
+                            met[lds2_sw(lds2_state_of(C, r, tid_o, SBITS), (u32)N)] = mA[r];
+                            if constexpr (GPT == 2) met[lds2_sw(lds2_state_of(C, r, tid_o + (u32)T, SBITS), (u32)N)] = mB[r];
                         });
                     }
                 }
             }
         });
-        __syncthreads();
+        if (tid == 0) flag[0] = nst == BLK ? predict(mA[0], t0 + BLK, set ^ 1) : 1u;
+        __syncthreads();                       // B2
+        return flag[0] != 0;
     };
-    // the fast version: four stages back to back, one barrier.  Returns true when thread 0 saw state 0 reach the threshold
-    // after stage 0, 1 or 2: the block's results are then void and the caller re-runs it with slow_block()
-    auto fast_block = [&](auto bufc, u32 t0) __attribute__((always_inline)) -> bool {
-        constexpr int buf = decltype(bufc)::value;
-        const u32* src = met + buf * N;
-        u32* dst = met + (buf ^ 1) * N;
-        // tables of the NEXT block from the symbols fetched during the previous one, then fetch the block after
-        tables_build(t0 + BLK, buf ^ 1);
+    // the fast version: four stages back to back between the two barriers.  Returns the prediction for the next block.
+    auto fast_block = [&](auto setc, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> bool {
+        constexpr int set = decltype(setc)::value;
+        // the metric loads go out first; behind them, while they are in flight: the tables of the NEXT block from the symbols
+        // fetched during the previous one, then the fetch for the block after
+        load_metrics();
+        tables_build(t0 + BLK, set ^ 1);
         tables_load(t0 + 2 * BLK);
-        load_metrics(src);
-        u32* const wsp = ws_pair + (size_t)t0 * T;   // uniform: the four decision rows of this block
-        u32 mid = 0;
+        // B1, split: "my loads have returned" is announced here (one LDS add per wavefront) ...
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
+        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        u32* const wsp = ws_pair + (size_t)t0 * G;   // uniform: the four decision rows of this block
+
+        // one group after the other (not stage by stage across both): only one group's temporaries are live at a time, which is
+        // what keeps two groups per thread (nearly) inside the 128 registers of a four-waves-per-SIMD kernel
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
-            constexpr int C = decltype(cc)::value;
-            stage(cc, (u32)(buf * BLK * 512), wsp);
-            if (C < BLK - 1 && wave == 0) mid |= (l2_sub_sat_s(THRM1B2, m[0]) | FORCE) & BIAS2;
+            stage(cc, mA, (u32)set * SET_TAB, wsp + decltype(cc)::value * G + tid);
         });
-        store_metrics(dst);
-        if (tid == 0) flag[buf] = mid;
-        __syncthreads();
-        if (flag[buf] != 0) return true;
+        if constexpr (GPT == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
+                stage(cc, mB, (u32)set * SET_TAB + 512u, wsp + decltype(cc)::value * G + T + tid);
+            });
+        }
+        // ... and awaited only here, four trellis steps later, before the first store: by now every wavefront has long arrived
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrive_target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        store_metrics();
+        if (tid == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);
+        __syncthreads();                       // B2
+        const bool pred = flag[0] != 0;
         // renormalise when new_metric[0] >= threshold after the block's last step: block-uniform
-        const u32 need = (l2_sub_sat_s(THRM1B2, dst[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
+        const u32 need = (l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
         if (need != 0) {
+            __syncthreads();                   // everybody has read met[0] and flag[0] before they can change
             renormalise(need);
-            store_metrics(dst);
+            store_metrics();
             __syncthreads();
         }
-        return false;
+        return pred;
     };
 
     u32 t0 = tb0;
-    int cur = 0;                              // metric / table buffer that holds the state of block t0
+    u32 arrivals_wanted = (u32)NW;            // value of *arrive once every wavefront has loaded the current block's metrics
+    int set = 0;                              // table set that holds block t0
+    bool careful = flag[0] != 0;
     while (t0 < a.t_end) {
         const u32 left = a.t_end - t0;
         const int nst = left < (u32)BLK ? (int)left : BLK;
         const int c_first = t0 < a.t_begin ? (int)(a.t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
-        // partial blocks (the entry block of a resumed call, the last block of a frame) take the careful routine; the tables
-        // of the last block were built by the block (or prologue) before it
-        bool slow = nst < BLK || c_first > 0;
-        if (!slow) slow = cur == 0 ? fast_block(std::integral_constant<int, 0>{}, t0) : fast_block(std::integral_constant<int, 1>{}, t0);
-        if (slow) slow_block(t0, cur, c_first, nst, c_first > 0);
+        if (nst < BLK || c_first > 0 || careful) careful = slow_block(t0, set, c_first, nst);
+        else careful = set == 0 ? fast_block(std::integral_constant<int, 0>{}, t0, arrivals_wanted) : fast_block(std::integral_constant<int, 1>{}, t0, arrivals_wanted);
+        arrivals_wanted += (u32)NW;
         t0 += (u32)BLK;
-        cur ^= 1;
+        set ^= 1;
     }
 
-    const u32* fin = met + cur * N;
     if (a.metrics_out) {
         for (int s = tid; s < N; s += T) {
-            const u32 v = fin[lds2_sw((u32)s, (u32)N)] ^ BIAS2;
+            const u32 v = met[lds2_sw((u32)s, (u32)N)] ^ BIAS2;
             if (SHIFT) {
                 ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
                 if (validB) ((uint8_t*)a.metrics_out)[(size_t)fB * N + s] = (uint8_t)(v >> 24);
@@ -533,6 +633,11 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)GM::smem_bytes) != hipSuccess)
             return -1;
+    }
+    if (getenv("VIT_HIP_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), GM::T, GM::smem_bytes);
+        fprintf(stderr, "lds2_update_kernel<%d>: %d threads, %zu B LDS per workgroup, %d workgroup(s) per CU\n", K, GM::T, GM::smem_bytes, nb);
     }
     hipLaunchKernelGGL(kern, dim3(pairs), dim3(GM::T), GM::smem_bytes, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -349,7 +349,7 @@ static int vit_hip_create_impl(int K, int R, int soft_bytes, int error_bytes, co
         const char* e = getenv("VIT_HIP_JIT");
         if (e && *e == '1') (void)try_reg_jit(h);   // opt-in at create time; vit_hip_set_plan(PLAN_REG) always tries
     }
-    h->lds2_ok = vit::lds2_supported(K, R);
+    h->lds2_ok = h->linear && vit::lds2_supported(K, R);   // the group-B tables rely on the code being linear
     h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
     *out = h;
     return VIT_HIP_OK;
