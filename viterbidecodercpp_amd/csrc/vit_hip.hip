@@ -75,6 +75,8 @@ struct vit_hip_decoder {
     hipStream_t stream = nullptr;
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* h_stage = nullptr;        // pinned host staging: one H2D and one D2H per host-route call
+    size_t stage_bytes = 0;
 };
 
 namespace {
@@ -186,6 +188,17 @@ int ensure_scratch(vit_hip_handle h, size_t bytes) {
     const size_t want = bytes + bytes / 2 + 4096;
     VIT_HIP_CHECK(hipMalloc(&h->d_scratch, want));
     h->scratch_bytes = want;
+    return VIT_HIP_OK;
+}
+
+int ensure_stage(vit_hip_handle h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return VIT_HIP_OK;
+    if (h->h_stage) VIT_HIP_CHECK(hipHostFree(h->h_stage));
+    h->h_stage = nullptr;
+    h->stage_bytes = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    VIT_HIP_CHECK(hipHostMalloc(&h->h_stage, want, hipHostMallocDefault));
+    h->stage_bytes = want;
     return VIT_HIP_OK;
 }
 
@@ -360,6 +373,7 @@ int vit_hip_destroy(vit_hip_handle h) {
     DeviceGuard guard(h->device);
     if (h->d_pattern) (void)hipFree(h->d_pattern);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return VIT_HIP_OK;
@@ -741,26 +755,46 @@ int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbo
     if (n_steps > 0x7FFFFFF0u) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps too large");
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
-    const size_t sym_b = align_up(n_steps * (size_t)h->R * (size_t)h->soft_bytes, 256);
-    const size_t dec_b = align_up(n_steps * (size_t)h->W * 8, 256);
-    const size_t met_b = align_up((size_t)h->N * (size_t)h->error_bytes, 256);
-    int rc = ensure_scratch(h, sym_b + dec_b + met_b + 256);
+    // device scratch and pinned staging share one layout: [metrics | renorm sum | symbols] in, [metrics | renorm sum | decision
+    // rows] out -- ONE copy each way per call (five pageable copies before: this route is called once per trellis step by
+    // streaming callers, examples/helpers/puncture_code_helpers.h:51)
+    const size_t sym_bytes = n_steps * (size_t)h->R * (size_t)h->soft_bytes;
+    const size_t dec_bytes = n_steps * (size_t)h->W * 8;
+    const size_t met_bytes = (size_t)h->N * (size_t)h->error_bytes;
+    const size_t met_b = align_up(met_bytes, 256), rs_b = 256;
+    const size_t sym_b = align_up(sym_bytes, 256), dec_b = align_up(dec_bytes, 256);
+    const size_t in_b = met_b + rs_b + sym_b;
+    int rc = ensure_scratch(h, in_b + dec_b);
+    if (rc != VIT_HIP_OK) return rc;
+    rc = ensure_stage(h, in_b + dec_b);
     if (rc != VIT_HIP_OK) return rc;
     uint8_t* base = (uint8_t*)h->d_scratch;
-    uint8_t* d_sym = base;
-    uint64_t* d_dec = (uint64_t*)(base + sym_b);
-    uint8_t* d_met = base + sym_b + dec_b;
-    uint64_t* d_rs = (uint64_t*)(base + sym_b + dec_b + met_b);
-    VIT_HIP_CHECK(hipMemcpyAsync(d_sym, symbols, n_steps * (size_t)h->R * (size_t)h->soft_bytes, hipMemcpyHostToDevice, h->stream));
-    VIT_HIP_CHECK(hipMemcpyAsync(d_met, metrics_inout, (size_t)h->N * (size_t)h->error_bytes, hipMemcpyHostToDevice, h->stream));
+    uint8_t* d_met = base;
+    uint64_t* d_rs = (uint64_t*)(base + met_b);
+    uint8_t* d_sym = base + met_b + rs_b;
+    uint64_t* d_dec = (uint64_t*)(base + in_b);
+    uint8_t* hs = (uint8_t*)h->h_stage;
+    memcpy(hs, metrics_inout, met_bytes);
+    memcpy(hs + met_b + rs_b, symbols, sym_bytes);
+    VIT_HIP_CHECK(hipMemcpyAsync(base, hs, met_b + rs_b + sym_bytes, hipMemcpyHostToDevice, h->stream));
     // streaming state lives on the host between calls, so this route always runs the LDS plan on one frame
     rc = lds_update(h, d_sym, n_steps * (size_t)h->R, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
     if (rc != VIT_HIP_OK) return rc;
+    // out: metrics and renorm sum sit in front of the symbols, the decision rows behind them: copy [metrics | rs] and the rows
+    // as one contiguous range when the symbols are short (the common streaming case), else as two
+    if (sym_b <= 4096) {
+        VIT_HIP_CHECK(hipMemcpyAsync(hs, base, in_b + dec_bytes, hipMemcpyDeviceToHost, h->stream));
+        VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(decisions_out, hs + in_b, dec_bytes);
+    } else {
+        VIT_HIP_CHECK(hipMemcpyAsync(hs, base, met_b + rs_b, hipMemcpyDeviceToHost, h->stream));
+        VIT_HIP_CHECK(hipMemcpyAsync(hs + met_b + rs_b, d_dec, dec_bytes, hipMemcpyDeviceToHost, h->stream));
+        VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(decisions_out, hs + met_b + rs_b, dec_bytes);
+    }
+    memcpy(metrics_inout, hs, met_bytes);
     uint64_t rs = 0;
-    VIT_HIP_CHECK(hipMemcpyAsync(decisions_out, d_dec, n_steps * (size_t)h->W * 8, hipMemcpyDeviceToHost, h->stream));
-    VIT_HIP_CHECK(hipMemcpyAsync(metrics_inout, d_met, (size_t)h->N * (size_t)h->error_bytes, hipMemcpyDeviceToHost, h->stream));
-    VIT_HIP_CHECK(hipMemcpyAsync(&rs, d_rs, 8, hipMemcpyDeviceToHost, h->stream));
-    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(&rs, hs + met_b, 8);
     if (renorm_sum_out) *renorm_sum_out = rs;
     return VIT_HIP_OK;
 }
