@@ -76,6 +76,19 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
     assert waits and all(int(w) > 0 for w in waits), waits
 
 
+@pytest.mark.parametrize("reg_id", [3, 4])
+def test_k9_update_kernels_do_not_spill(tmp_path, reg_id):
+    """K = 9 (64 metric registers per lane): CDMA IS-95A must fit two waves per SIMD (256 registers) and CDMA 2000 one, both
+    without scratch -- the chunked decision gather in reg_update_body is what makes room."""
+    _, usage = _compile("reg_inst.hip", [f"-DVIT_REG_ID={reg_id}"], tmp_path)
+    upd = [k for k in usage if "reg_update_kernel" in k]
+    assert len(upd) == 2
+    for k in upd:
+        assert usage[k]["ScratchSize"] == 0, (k, usage[k])
+        if reg_id == 3:
+            assert usage[k]["VGPRs"] + usage[k].get("AGPRs", 0) <= 256, (k, usage[k])
+
+
 def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
     asm, usage = _compile("vit_hip.hip", [], tmp_path)
     k15 = [k for k in usage if "lds2_update_kernelILi15ELi0" in k]

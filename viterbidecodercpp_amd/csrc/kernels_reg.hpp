@@ -554,30 +554,14 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 // ---- add-compare-select, in place  (scalar.h:113-134) ----
                 // biased metrics: x > y (unsigned, reference)  <=>  sign of sat_i16(y' - x'); min is the signed min
                 u32 D[NREG];
-                static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
-                    constexpr int h = decltype(hc)::value;
-                    // h enumerates the NREG/2 register indices with bit PB clear
-                    constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
-                    constexpr int r1 = r0 | (1 << PB);
-                    constexpr u32 p = SP::pat_reg(PH, (u32)r0);
-                    const u32 ma = m[r0], mb = m[r1];
-                    const u32 x0 = pk_add(ma, E[cur][p]), y0 = pk_add(mb, EB[cur][p]);   // -> next state (X|0)
-                    const u32 x1 = pk_add(ma, EB[cur][p]), y1 = pk_add(mb, E[cur][p]);   // -> next state (X|1)
-                    m[r0] = pk_min_s(x0, y0);
-                    m[r1] = pk_min_s(x1, y1);
-                    D[r0] = pk_sub_sat_s(y0, x0);   // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
-                    D[r1] = pk_sub_sat_s(y1, x1);
-                });
-                // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
-                const u32 need = (pk_sub_sat_s_uniform(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
-                // ---- gather the 2 x NREG sign bits.  v_perm_b32 selectors 8..11 replicate the sign of a 16-bit half over a
-                //      whole byte, so one perm of the register pair (r, r+8) yields four CLEAN bytes (0x00 / 0xFF):
-                //      {A r, B r, A r+8, B r+8}; pair j then drops into bit j of every byte with a single v_and_or (no shift
-                //      chain).  One dword per 16 registers: byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B
+                // ---- ... and, chunk by chunk, the gather of the 2 x NREG sign bits.  v_perm_b32 selectors 8..11 replicate the
+                //      sign of a 16-bit half over a whole byte, so one perm of the register pair (r, r+8) yields four CLEAN bytes
+                //      (0x00 / 0xFF): {A r, B r, A r+8, B r+8}; pair j then drops into bit j of every byte with a single v_and_or
+                //      (no shift chain).  One dword per 16 registers: byte 0/1 = frame A/B registers 0-7, byte 2/3 = frame A/B
                 //      registers 8-15, register k at bit k%8 ----
                 constexpr u32 SIGN_BYTES = 0x0b0a0908u;
                 u32 acc[DW];
-                static_for<DW>([&](auto dc) __attribute__((always_inline)) {
+                auto gather = [&](auto dc) __attribute__((always_inline)) {
                     constexpr int d = decltype(dc)::value;
                     auto dreg = [&](auto rc) __attribute__((always_inline)) -> u32 {   // fewer than 16 registers: K < 7
                         constexpr int rr = decltype(rc)::value;
@@ -596,7 +580,40 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         ch = and_or(ph, 0x10101010u << k, ch);
                     });
                     acc[d] = ch;
+                };
+                // 64-register codes (K = 9): a 16-register chunk is gathered as soon as its butterflies are done and the
+                // scheduler may not move work across that point -- 64 metrics + 64 live decision values + branch metrics + index
+                // registers do not fit 256 registers (hipcc spilled 24 bytes per lane and reloaded them twice per step)
+                constexpr bool CHUNKED = NREG >= 64;
+                static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
+                    constexpr int h = decltype(hc)::value;
+                    // h enumerates the NREG/2 register indices with bit PB clear
+                    constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
+                    constexpr int r1 = r0 | (1 << PB);
+                    constexpr u32 p = SP::pat_reg(PH, (u32)r0);
+                    const u32 ma = m[r0], mb = m[r1];
+                    const u32 x0 = pk_add(ma, E[cur][p]), y0 = pk_add(mb, EB[cur][p]);   // -> next state (X|0)
+                    const u32 x1 = pk_add(ma, EB[cur][p]), y1 = pk_add(mb, E[cur][p]);   // -> next state (X|1)
+                    m[r0] = pk_min_s(x0, y0);
+                    m[r1] = pk_min_s(x1, y1);
+                    D[r0] = pk_sub_sat_s(y0, x0);   // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
+                    D[r1] = pk_sub_sat_s(y1, x1);
+                    if constexpr (CHUNKED) {
+                        if constexpr (PB <= 3) {
+                            // the pair bit lies inside a chunk: butterflies 8k .. 8k+7 complete registers 16k .. 16k+15
+                            if constexpr ((h & 7) == 7) { gather(std::integral_constant<int, h / 8>{}); __builtin_amdgcn_sched_barrier(0); }
+                        } else if constexpr ((h & 15) == 15) {
+                            // pairs (r, r + 16) or (r, r + 32): sixteen butterflies complete the two chunks of their r0 and r1
+                            constexpr int c0 = (((h - 15) >> PB) << (PB + 1) | ((h - 15) & ((1 << PB) - 1))) / 16;
+                            gather(std::integral_constant<int, c0>{});
+                            gather(std::integral_constant<int, c0 + (1 << (PB - 4))>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 });
+                // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
+                const u32 need = (pk_sub_sat_s_uniform(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
+                if constexpr (!CHUNKED) static_for<DW>([&](auto dc) __attribute__((always_inline)) { gather(dc); });
                 if constexpr (LP && NREG == 16) {
                     // registers 0-7 / 8-15 (low / high half of the dword) belong to different lanes until the exchange is
                     // undone: lane bit 0 keeps its low half and takes the partner's low half as its high half; lane bit 1
