@@ -96,10 +96,10 @@ def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
     u = usage[k15[0]]
     # 512 threads per workgroup, two workgroups per CU = 4 waves per SIMD: 128 registers at most
     assert u["VGPRs"] + u.get("AGPRs", 0) <= 128, u
-    # two radix-16 groups per thread do not quite fit: hipcc keeps the 32 table offsets unpacked and spills some of them.
-    # Bound the damage: a fast block (the code between two workgroup barriers that holds the 64 table reads and the eight
-    # 16-byte metric stores) may reload at most 12 of them and must never spill inside the block
-    assert u["ScratchSize"] <= 128, u
+    # two radix-16 groups per thread sit right at that budget: a few loop-invariant values of the prologue / careful path may
+    # live in scratch, but the fast block (the code between two workgroup barriers that holds the 64 table reads and the
+    # eight 16-byte metric stores; ONE copy serves both table sets) may reload at most 4 of them and never spills
+    assert u["ScratchSize"] <= 32, u
     body = _kernel_body(asm, r"_ZN3vit18lds2_update_kernelILi15ELi0EEEvNS_14Lds2UpdateArgsE")
     seg, fast = [], []
     for l in body.split("\n") + ["s_barrier"]:
@@ -109,9 +109,9 @@ def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
             seg = []
         else:
             seg.append(l)
-    assert len(fast) == 2, len(fast)          # one copy per table set
+    assert len(fast) == 1, len(fast)
     for seg in fast:
-        assert sum("scratch_load" in x for x in seg) <= 12, "the fast path reloads too many spilled registers"
+        assert sum("scratch_load" in x for x in seg) <= 4, "the fast path reloads too many spilled registers"
         assert not any("scratch_store" in x for x in seg), "the fast path spills"
         # exactly one hardware barrier per block: the first one is split into an LDS arrive / await pair
         assert sum("ds_add_u32" in x for x in seg) >= 1

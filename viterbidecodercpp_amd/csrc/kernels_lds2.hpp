@@ -78,6 +78,7 @@ struct Lds2UpdateArgs {
     u32 frames;
     u32 t_begin, t_end;              // trellis steps [t_begin, t_end) of every frame; the symbol chunk starts at step t_begin
     int32_t R;
+    uint8_t idx_f[4], idx_t[4];      // per block stage: the bank-conflict-free table index map (lds2_tab_index)
     DevConfig cfg;
 };
 
@@ -110,6 +111,20 @@ __host__ __device__ inline void lds2_locate(u32 s, u32 t, int sbits, u32& j, u32
 __host__ __device__ constexpr u32 lds2_sw(u32 s, u32 n) {
     const u32 q = (s >> 2) & 3u;
     return q * (n / 4u) + (((s >> 4) ^ (q << 1)) << 2) + (s & 3u);
+}
+
+// Position of pattern p inside a step's 64-entry branch-metric table.  A ds_read_b64 serves lanes 0-31 and 32-63 in one LDS
+// cycle each if no two lanes of a group need DIFFERENT entries that share banks, i.e. entries whose positions differ only
+// in bit 5.  The patterns the 32 lanes of a group ask for in stage c form a coset of the linear space V_c spanned by the
+// patterns of five state bits, so a position map that is linear in p and sends V_c into {bit 5 = 0} makes every table read
+// conflict free: bit 5 = parity(p & f) for an f orthogonal to V_c (one exists: dim V_c <= 5 < 6), bits 0-4 = p without its
+// bit t, where t is a set bit of f (which makes the map a bijection).  In natural order a third of the read cycles were
+// bank conflicts (SQ_LDS_BANK_CONFLICT 11 % of all LDS cycles).
+__host__ __device__ constexpr u32 lds2_tab_index(u32 p, u32 f, u32 t) {
+    const u32 low = (p & ((1u << t) - 1u)) | ((p >> (t + 1u)) << t);
+    u32 x = p & f;
+    x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
+    return low | ((x & 1u) << 5);
 }
 
 template <int K>
@@ -181,7 +196,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
                 constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
                 const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
                 // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + SET_TAB, an instruction offset)
-                const u32 off = (u32)C * STEP_TAB + ((u32)a.pattern[lower] & 63u) * 8u;
+                const u32 off = (u32)C * STEP_TAB + lds2_tab_index((u32)a.pattern[lower] & 63u, a.idx_f[C], a.idx_t[C]) * 8u;
                 pk |= off << (16 * decltype(ec)::value);
             });
             prow2[C][h2] = pk;
@@ -239,8 +254,9 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 #pragma unroll
         for (int c = 0; c < BLK; ++c) xorB[c] = (u32)a.pattern[(size_t)1 << (GM::JB - 1 + c)] & 63u;
     }
-    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb) __attribute__((always_inline)) {
-        // E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107)
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
+        // lane p: E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107),
+        // stored at position lds2_tab_index(p)
         u32 e = 0, eb = 0;
         const u32 pb = (u32)lane ^ xb;
 #pragma unroll
@@ -252,29 +268,46 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
                 eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
             }
         }
-        tab[lane] = make_uint2(e, l2_sub(MAXE2, e));
-        if constexpr (GPT == 2) tab[64 + lane] = make_uint2(eb, l2_sub(MAXE2, eb));   // entry p of the group-B table = E[p ^ xb]
+        tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
+        if constexpr (GPT == 2) tab[64 + pos] = make_uint2(eb, l2_sub(MAXE2, eb));   // the group-B table holds E[p ^ xb] where A holds E[p]
     };
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
     constexpr int CPW = GM::CPW;
-    u32 ysym[CPW][6];                        // lds2_supported(): R <= 6
+    // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
+    // closing barrier) and are moved to SGPRs right behind it (tables_commit), so that no vector register carries them through
+    // the block's compute phase -- at 128 registers per thread every one of them was a spill.
+    u32 yland[CPW][6];                       // lds2_supported(): R <= 6
+    u32 ysym[CPW][6];                        // wave-uniform
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ysym[i][k] = 0;
+        for (int k = 0; k < 6; ++k) { yland[i][k] = 0; ysym[i][k] = 0; }
+    u32 tabpos[CPW];                         // where this lane's entry goes in the tables this wavefront builds (lds2_tab_index)
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = (wave + NW * i) & (BLK - 1);
+        tabpos[i] = lds2_tab_index((u32)lane, a.idx_f[c], a.idx_t[c]);
+    }
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) load_syms(t0 + (u32)c, ysym[i]);
+            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) load_syms(t0 + (u32)c, yland[i]);
         }
+    };
+    auto tables_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ysym[i][k] = (u32)__builtin_amdgcn_readfirstlane((int)yland[i][k]);
     };
     auto tables_build = [&](u32 t0, int set) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
             if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin)
-                build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], c == 0 ? xorB[0] : c == 1 ? xorB[1] : c == 2 ? xorB[2] : xorB[3]);
+                build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], c == 0 ? xorB[0] : c == 1 ? xorB[1] : c == 2 ? xorB[2] : xorB[3],
+                            tabpos[i]);
         }
     };
     // thread 0: could state 0 reach the threshold after one of the first three steps of the block at t_next, whose tables
@@ -295,8 +328,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     };
     const u32 tb0 = a.t_begin & ~(u32)(BLK - 1);   // the block that holds step t_begin (0 for a fresh decode)
     tables_load(tb0);
+    tables_commit();
     tables_build(tb0, 0);
     tables_load(tb0 + BLK);
+    tables_commit();
     __syncthreads();
     if (tid == 0) flag[0] = predict(met[0], tb0, 0);
     __syncthreads();
@@ -304,9 +339,9 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
     u32 mA[16], mB[GPT == 2 ? 16 : 1];
-    // one trellis step on the 16 registers of one group: stage C of a block, tables at `tab_off` from the packed offsets,
+    // one trellis step on the 16 registers of one group: stage C of a block, table entries at addr[h] + tab_off,
     // decisions of the step -> one dword  (scalar.h:113-134)
-    auto stage = [&](auto cc, u32 (&m)[16], u32 tab_off, u32* wdst) __attribute__((always_inline)) {
+    auto stage = [&](auto cc, u32 (&m)[16], const u32 (&addr)[8], u32 tab_off, u32* wdst) __attribute__((always_inline)) {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
         // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
         // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
@@ -315,8 +350,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value;
             constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
-            const u32 off = (h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu);
-            const uint2 ee = *(const uint2*)((const char*)lds2_smem + off + tab_off);
+            const uint2 ee = *(const uint2*)((const char*)lds2_smem + addr[h] + tab_off);
             const u32 ma = m[r0], mb = m[r1];
             const u32 x0 = l2_add(ma, ee.x), y0 = l2_add(mb, ee.y);   // -> next state 2a
             const u32 x1 = l2_add(ma, ee.y), y1 = l2_add(mb, ee.x);   // -> next state 2a+1
@@ -333,10 +367,21 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         });
         *wdst = lo4;
     };
-    auto stage_all = [&](auto cc, int set, u32* wsp) __attribute__((always_inline)) {   // wsp: decision row of block step 0
+    // stage C of every group of this thread.  The eight table offsets of the stage are unpacked HERE from their packed
+    // registers, once for both groups: the packed words change with every block (the table-set bit is toggled in them), so
+    // the unpacked values cannot be hoisted out of the block loop -- hoisted, they were 32 loop-invariant registers that
+    // the 128-register budget does not have (hipcc spilled 9-22 of them, and every reload's s_waitcnt vmcnt also waited for
+    // the decision stores in flight)
+    auto stage_all = [&](auto cc, u32* wsp) __attribute__((always_inline)) {   // wsp: decision row of block step 0
         constexpr int C = decltype(cc)::value;
-        stage(cc, mA, (u32)set * SET_TAB, wsp + C * G + tid);
-        if constexpr (GPT == 2) stage(cc, mB, (u32)set * SET_TAB + 512u, wsp + C * G + T + tid);
+        u32 addr[8];
+        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
+            addr[h] = (h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu);
+        });
+        stage(cc, mA, addr, 0u, wsp + C * G + tid);
+        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, wsp + C * G + T + tid);
+        __builtin_amdgcn_sched_barrier(0);
     };
     // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
     constexpr bool SEP = (G / 16) % 8 == 0;     // r*G/16 does not reach the three bits the swizzle touches: base + r*G/4
@@ -407,6 +452,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     auto slow_block = [&](u32 t0, int set, int c_first, int nst) __attribute__((always_inline)) -> bool {
         tables_build(t0 + BLK, set ^ 1);       // nobody has built the next block's tables yet
         tables_load(t0 + 2 * BLK);
+        tables_commit();
         // an opaque copy of the thread index: the scatter / gather addresses below are loop invariant, and hoisted out of the
         // main loop they would cost the FAST path its registers for a once-per-frame use
         u32 tid_o = (u32)tid;
@@ -425,7 +471,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
             if (C >= c_first && C < nst) {
-                stage_all(cc, set, ws_pair + (size_t)t0 * G);
+                stage_all(cc, ws_pair + (size_t)t0 * G);
                 // state 0 is register 0 of thread 0's first group after every stage
                 if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
                 __syncthreads();
@@ -450,35 +496,25 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         return flag[0] != 0;
     };
     // the fast version: four stages back to back between the two barriers.  Returns the prediction for the next block.
-    auto fast_block = [&](auto setc, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> bool {
-        constexpr int set = decltype(setc)::value;
+    auto fast_block = [&](int set, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> bool {
         // the metric loads go out first; behind them, while they are in flight: the tables of the NEXT block from the symbols
-        // fetched during the previous one, then the fetch for the block after
+        // fetched during the previous one
         load_metrics();
         tables_build(t0 + BLK, set ^ 1);
-        tables_load(t0 + 2 * BLK);
         // B1, split: "my loads have returned" is announced here (one LDS add per wavefront) ...
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
         if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         u32* const wsp = ws_pair + (size_t)t0 * G;   // uniform: the four decision rows of this block
 
-        // one group after the other (not stage by stage across both): only one group's temporaries are live at a time, which is
-        // what keeps two groups per thread (nearly) inside the 128 registers of a four-waves-per-SIMD kernel
-        l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
-            stage(cc, mA, (u32)set * SET_TAB, wsp + decltype(cc)::value * G + tid);
-        });
-        if constexpr (GPT == 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
-                stage(cc, mB, (u32)set * SET_TAB + 512u, wsp + decltype(cc)::value * G + T + tid);
-            });
-        }
+        l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) { stage_all(cc, wsp); });
         // ... and awaited only here, four trellis steps later, before the first store: by now every wavefront has long arrived
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrive_target) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        tables_load(t0 + 2 * BLK);             // the symbols of the block after next: in flight across the barrier
         store_metrics();
         if (tid == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);
         __syncthreads();                       // B2
+        tables_commit();
         const bool pred = flag[0] != 0;
         // renormalise when new_metric[0] >= threshold after the block's last step: block-uniform
         const u32 need = (l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
@@ -500,7 +536,12 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         const int nst = left < (u32)BLK ? (int)left : BLK;
         const int c_first = t0 < a.t_begin ? (int)(a.t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
         if (nst < BLK || c_first > 0 || careful) careful = slow_block(t0, set, c_first, nst);
-        else careful = set == 0 ? fast_block(std::integral_constant<int, 0>{}, t0, arrivals_wanted) : fast_block(std::integral_constant<int, 1>{}, t0, arrivals_wanted);
+        else careful = fast_block(set, t0, arrivals_wanted);
+        // the next block reads the other table set: flip the set bit in all packed offsets
+#pragma unroll
+        for (int c = 0; c < BLK; ++c)
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) prow2[c][h2] ^= SET_TAB * 0x10001u;
         arrivals_wanted += (u32)NW;
         t0 += (u32)BLK;
         set ^= 1;
@@ -655,7 +696,26 @@ int lds2_launch_update_k(int K, const Lds2UpdateArgs& a, unsigned pairs, hipStre
     }
 }
 
-inline int lds2_update(int K, int R, const DevConfig& cfg, int shift, const uint16_t* d_pattern, const void* d_symbols,
+// the per-stage table index maps (lds2_tab_index) from the host copy of the branch patterns
+inline void lds2_index_maps(int K, const uint16_t* pattern, uint8_t (&f_out)[4], uint8_t (&t_out)[4]) {
+    for (int c = 0; c < 4; ++c) {
+        // lanes 0-31 of a wavefront differ in thread-index bits 0-4 = butterfly-index bits c .. c+4 in stage c
+        uint32_t basis[5];
+        for (int i = 0; i < 5; ++i) basis[i] = pattern[(size_t)1 << (c + i)] & 63u;
+        uint32_t f = 0;
+        for (uint32_t cand = 1; cand < 64 && !f; ++cand) {
+            bool ok = true;
+            for (int i = 0; i < 5; ++i) ok = ok && ((__builtin_popcount(cand & basis[i]) & 1) == 0);
+            if (ok) f = cand;
+        }
+        if (!f) f = 32;     // cannot happen (five vectors never span six dimensions); natural order
+        f_out[c] = (uint8_t)f;
+        t_out[c] = (uint8_t)(31 - __builtin_clz(f));
+    }
+    (void)K;
+}
+
+inline int lds2_update(int K, int R, const DevConfig& cfg, int shift, const uint16_t* d_pattern, const uint16_t* h_pattern, const void* d_symbols,
                        size_t sym_stride, size_t frames, size_t first_step, size_t n_steps, size_t L, void* d_ws,
                        const void* d_metrics_in, void* d_metrics, uint64_t* d_renorm, const uint32_t* d_start, hipStream_t st) {
     if (frames == 0 || n_steps == 0) return 0;
@@ -668,6 +728,7 @@ inline int lds2_update(int K, int R, const DevConfig& cfg, int shift, const uint
     a.renorm_sum = d_renorm;
     a.start_state = d_start;
     a.pattern = d_pattern;
+    lds2_index_maps(K, h_pattern, a.idx_f, a.idx_t);
     a.metrics_in = d_metrics_in;
     a.frames = (u32)frames;
     a.t_begin = (u32)first_step;

@@ -483,7 +483,7 @@ int update_batch_impl(vit_hip_handle h, const void* d_symbols, size_t sym_stride
         return VIT_HIP_OK;
     }
     if (h->plan == VIT_HIP_PLAN_LDS2) {
-        const int rc = vit::lds2_update(h->K, h->R, h->cfg, h->shift, h->d_pattern, d_symbols, sym_stride, frames, first_step,
+        const int rc = vit::lds2_update(h->K, h->R, h->cfg, h->shift, h->d_pattern, h->pattern.data(), d_symbols, sym_stride, frames, first_step,
                                         n_steps, L, d_workspace, d_metrics_in, d_metrics_out, d_renorm_sum, d_start_state, st);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "PLAN_LDS2 update launch failed");
         return VIT_HIP_OK;
