@@ -65,7 +65,7 @@ extern "C" {
                                The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32
-                               metrics double-buffered in LDS (K = 11..15, R <= 6, any polynomials)                  */
+                               metrics updated in place in LDS (K = 11..16, R <= 6, any polynomials)                   */
 
 typedef struct vit_hip_decoder* vit_hip_handle;
 typedef void* vit_hip_stream_t;

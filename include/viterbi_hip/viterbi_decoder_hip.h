@@ -14,10 +14,10 @@ template <size_t constraint_length, size_t code_rate, typename error_t, typename
 class ViterbiDecoder_HIP {
 public:
     using Base = ViterbiDecoder_Core<constraint_length, code_rate, error_t, soft_t>;
-    // what libvit_hip.so serves: 2 <= K <= 15 (both metric buffers of a frame live in the 160 KiB LDS), R <= 8,
+    // what libvit_hip.so serves: 2 <= K <= 16 (the state metrics of a frame live in the 160 KiB LDS of one CU), R <= 8,
     // (int16_t,uint16_t) or (int8_t,uint8_t)
     static constexpr bool is_valid =
-        Base::K >= 2 && Base::K <= 15 && Base::R >= 1 && Base::R <= 8 &&
+        Base::K >= 2 && Base::K <= 16 && Base::R >= 1 && Base::R <= 8 &&
         ((std::is_same<soft_t, int16_t>::value && std::is_same<error_t, uint16_t>::value) ||
          (std::is_same<soft_t, int8_t>::value && std::is_same<error_t, uint8_t>::value));
 

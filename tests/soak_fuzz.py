@@ -26,7 +26,7 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
              (COMMON_CODES[5], _lib.PLAN_REG), (COMMON_CODES[6], _lib.PLAN_REG), (COMMON_CODES[0], _lib.PLAN_REG),
              (COMMON_CODES[1], _lib.PLAN_REG), (Code("K11", 11, 2, (0o3345, 0o3613)), _lib.PLAN_LDS2),
              (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), _lib.PLAN_LDS2), (COMMON_CODES[7], _lib.PLAN_LDS2),
-             (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS)]
+             (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS), (Code("K16", 16, 2, (46749, 58851)), _lib.PLAN_LDS2)]
     t_end = time.time() + budget_seconds
     seed, n = first_seed, 0
     while time.time() < t_end:
@@ -40,7 +40,7 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
                 config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
                                                cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
                 F = int(rng.integers(1, 70)) if code.K < 11 else int(rng.integers(1, 5))
-                L = int(rng.integers(1, 200)) if code.K < 11 else (int(rng.integers(1, 60)) if code.K < 15 else int(rng.integers(1, 24)))
+                L = int(rng.integers(1, 200)) if code.K < 11 else (int(rng.integers(1, 60)) if code.K < 15 else int(rng.integers(1, 24)) if code.K == 15 else int(rng.integers(1, 12)))
                 S = L + code.K - 1
                 lim = 1 << (8 * width - 1)
                 if rng.integers(0, 2):

@@ -21,6 +21,8 @@ CASES = [
     (COMMON_CODES[6], [_lib.PLAN_REG]),
     (Code("K11", 11, 2, (0o3345, 0o3613)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
     (COMMON_CODES[7], [_lib.PLAN_LDS2]),
+    # K = 16: one 1024-thread workgroup per CU, 128 KiB of metrics updated in place; the LDS plan reads its patterns from L2
+    (Code("K16", 16, 2, (46749, 58851)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
 ]
 
 
@@ -49,7 +51,7 @@ def test_random_configs_all_plans(oracle, case, width):
         config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
                                        cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
         F = int(rng.integers(1, 40)) if code.K < 11 else 3
-        L = int(rng.integers(1, 30)) * 8 if code.K < 15 else 16
+        L = int(rng.integers(1, 30)) * 8 if code.K < 15 else 16 if code.K == 15 else 8
         S = L + code.K - 1
         lim = 1 << (8 * width - 1)
         if trial % 2 == 0:      # in-range symbols

@@ -23,6 +23,7 @@ CASES = [
     (COMMON_CODES[1], "SOFT8", _lib.PLAN_REG, 130, 104),      # K5
     (K11, "SOFT16", _lib.PLAN_LDS2, 5, 72),
     (COMMON_CODES[7], "SOFT16", _lib.PLAN_LDS2, 3, 40),       # K15
+    (Code("K16 R=1/2", 16, 2, (46749, 58851)), "SOFT16", _lib.PLAN_LDS2, 3, 24),
     (K6, "SOFT16", _lib.PLAN_LDS, 4, 88),
     (COMMON_CODES[2], "SOFT16", _lib.PLAN_LDS, 3, 88),
 ]

@@ -54,7 +54,7 @@ def test_argument_errors_come_before_device_access():
     cfg = np.zeros(4, dtype=np.uint16)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     assert lib.vit_hip_create(1, 2, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
-    assert lib.vit_hip_create(16, 2, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_create(17, 2, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_create(7, 9, 2, 2, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_create(7, 2, 2, 1, p(tbl), p(cfg), 0, C.byref(h)) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_create(7, 2, 2, 2, None, p(cfg), 0, C.byref(h)) == _lib.ERR_INVALID_ARG

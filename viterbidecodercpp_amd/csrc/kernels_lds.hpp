@@ -56,10 +56,13 @@ __global__ void lds_update_kernel(LdsUpdateArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const size_t f = blockIdx.x;
 
+    // K = 16: two 64 KiB metric buffers leave no room for the 32 KiB pattern table: it is then read from global memory (L2)
+    const bool pat_in_lds = N <= 16384;
     uint16_t* met_old = smem;
     uint16_t* met_new = smem + N;
-    uint16_t* pat = smem + 2 * N;                 // [max(H,1)]
-    uint16_t* wmin = pat + (H > 0 ? H : 1);       // [nwaves]
+    uint16_t* pat_lds = smem + 2 * N;             // [max(H,1)] when pat_in_lds
+    uint16_t* wmin = pat_in_lds ? pat_lds + (H > 0 ? H : 1) : pat_lds;   // [nwaves]
+    const uint16_t* pat = pat_in_lds ? pat_lds : a.pattern;
 
     const int npw = (N >= 64 * nwaves) ? N / nwaves : N;  // next-states per wave
     const int ch = npw >= 64 ? npw / 64 : 1;              // 64-state chunks per wave per step
@@ -69,7 +72,8 @@ __global__ void lds_update_kernel(LdsUpdateArgs a) {
     while ((1 << chs) < ch) chs++;
 
     // ---- prime LDS: branch patterns + starting metrics (ViterbiDecoder_Core::reset, core.h:202-211) ----
-    for (int j = tid; j < (H > 0 ? H : 1); j += blockDim.x) pat[j] = a.pattern[j];
+    if (pat_in_lds)
+        for (int j = tid; j < (H > 0 ? H : 1); j += blockDim.x) pat_lds[j] = a.pattern[j];
     if (a.reset) {
         const uint32_t start = a.start_state ? (a.start_state[f] & (uint32_t)(N - 1)) : 0u;
         for (int s = tid; s < N; s += blockDim.x) met_old[s] = (s == (int)start) ? a.cfg.init_start : a.cfg.init_non_start;

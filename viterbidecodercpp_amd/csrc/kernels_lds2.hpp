@@ -1,4 +1,4 @@
-// kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 11..15, any polynomials): one workgroup per frame PAIR,
+// kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 11..16, any polynomials): one workgroup per frame PAIR,
 // state metrics of both frames packed in one u32 per state and double-buffered in LDS, FOUR trellis steps per barrier.
 //
 // Device implementation of the reference's scalar strategy
@@ -136,11 +136,12 @@ struct Lds2Geom {
     static constexpr int T = G / GPT, NW = T / 64;
     static constexpr int BLK = 4;                          // trellis steps per block
     static constexpr int CPW = (BLK + NW - 1) / NW;        // tables a wavefront builds per block
-    // K = 15: 512 threads and 72 KiB of LDS per workgroup, so that TWO workgroups share a CU (4 waves per SIMD, 128 VGPRs)
-    static constexpr int MINW = K == 15 ? 4 : 2;
+    // K = 15: 512 threads and 72 KiB of LDS per workgroup, so that TWO workgroups share a CU (4 waves per SIMD, 128 VGPRs);
+    // K = 16: 1024 threads and 136 KiB, one workgroup per CU -- what the in-place update makes possible at all
+    static constexpr int MINW = K >= 15 ? 4 : 2;
     static constexpr size_t tab_bytes = (size_t)2 * BLK * GPT * 64 * 8;
     static constexpr size_t smem_bytes = tab_bytes + 32 * 4 + (size_t)N * 4;
-    static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..15");
+    static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..16");
 };
 
 // One workgroup per frame pair.  The N packed metrics live in ONE LDS buffer that a block of four trellis steps updates IN
@@ -660,7 +661,7 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-inline bool lds2_supported(int K, int R) { return K >= 11 && K <= 15 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
+inline bool lds2_supported(int K, int R) { return K >= 11 && K <= 16 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
 inline size_t lds2_threads(int K) { return ((size_t)1 << (K - 1)) / 16; }
 inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
     return ((frames + 1) / 2) * (L + (size_t)K - 1) * lds2_threads(K) * 4;
@@ -692,6 +693,7 @@ int lds2_launch_update_k(int K, const Lds2UpdateArgs& a, unsigned pairs, hipStre
         case 13: return lds2_launch_update<13, SHIFT>(a, pairs, st);
         case 14: return lds2_launch_update<14, SHIFT>(a, pairs, st);
         case 15: return lds2_launch_update<15, SHIFT>(a, pairs, st);
+        case 16: return lds2_launch_update<16, SHIFT>(a, pairs, st);
         default: return -1;
     }
 }

@@ -89,7 +89,8 @@ int lds_waves(int N) {
 
 size_t lds_smem_bytes(int N, int waves) {
     const int H = N / 2;
-    return (size_t)(2 * N + (H > 0 ? H : 1) + waves) * sizeof(uint16_t);
+    const int pat = N <= 16384 ? (H > 0 ? H : 1) : 0;     // K = 16 reads the patterns from global memory (kernels_lds.hpp)
+    return (size_t)(2 * N + pat + waves) * sizeof(uint16_t);
 }
 
 template <int R, int SHIFT>
@@ -287,7 +288,7 @@ static int vit_hip_create_impl(int K, int R, int soft_bytes, int error_bytes, co
     if (!out) return fail(VIT_HIP_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (!branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "branch_table/config is NULL");
-    if (K < 2 || K > 15) return fail(VIT_HIP_ERR_UNSUPPORTED, "constraint length K must be 2..15 (2^(K-1) u16 metrics x2 in LDS)");
+    if (K < 2 || K > 16) return fail(VIT_HIP_ERR_UNSUPPORTED, "constraint length K must be 2..16 (the 2^(K-1) state metrics of a frame pair live in one CU's LDS)");
     if (R < 1 || R > 8) return fail(VIT_HIP_ERR_UNSUPPORTED, "code rate R must be 1..8");
     if (!((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
         return fail(VIT_HIP_ERR_UNSUPPORTED, "(soft_t,error_t) must be (int16_t,uint16_t) or (int8_t,uint8_t)");
@@ -402,7 +403,7 @@ static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
                         (g_last_error.empty() ? std::string("K must be 3,4,5,7 or 9, R <= 4, linear branch table") : g_last_error));
     }
     if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
-        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 11..15 with R <= 6 (see kernels_lds2.hpp)");
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 11..16 with R <= 6 and a linear branch table (see kernels_lds2.hpp)");
     if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG && plan != VIT_HIP_PLAN_LDS2)
         return fail(VIT_HIP_ERR_INVALID_ARG, "unknown plan");
     h->plan = plan;
@@ -435,7 +436,7 @@ static int vit_hip_create_from_blob_impl(const void* blob, size_t blob_bytes, in
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != BLOB_MAGIC) return fail(VIT_HIP_ERR_INVALID_ARG, "bad blob magic");
     // the header is untrusted: validate before any size arithmetic
-    if (hd.K < 2 || hd.K > 15 || hd.R < 1 || hd.R > 8 ||
+    if (hd.K < 2 || hd.K > 16 || hd.R < 1 || hd.R > 8 ||
         !((hd.soft_bytes == 2 && hd.error_bytes == 2) || (hd.soft_bytes == 1 && hd.error_bytes == 1)))
         return fail(VIT_HIP_ERR_INVALID_ARG, "corrupt blob header");
     const size_t need = vit_hip_blob_bytes(hd.K, hd.R, hd.soft_bytes, hd.error_bytes);
@@ -626,7 +627,7 @@ const RcclApi* rccl_api() {
 static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
                             void* branch_table, void* config, int device, vit_hip_stream_t stream) {
     if (!nccl_comm || !branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
-    if (K < 2 || K > 15 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
+    if (K < 2 || K > 16 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
         return fail(VIT_HIP_ERR_UNSUPPORTED, "unsupported (K, R, soft_t, error_t)");
     const size_t need = vit_hip_blob_bytes(K, R, soft_bytes, error_bytes);
     const RcclApi* api = rccl_api();
