@@ -959,12 +959,14 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
 
 template <class SP>
 VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
-    static_assert(SP::LANE_BITS == 0 && SP::NREG <= 16 && SP::DW == 1 && SP::SPS == 4, "small-K layout");
-    constexpr int SB = SP::SB;
+    // LANE_BITS = 0 (K <= 6): every state of a frame sits in ONE lane's registers, so one lane per frame chases its survivor
+    // through rows it loads itself.  A 16-byte row holds SPS = 4 / DW trellis steps of DW decision dwords (DW = 1: up to 16
+    // registers, K <= 5; DW = 2: 32 registers, K = 6).
+    static_assert(SP::LANE_BITS == 0 && SP::NREG <= 32 && (SP::DW == 1 || SP::DW == 2), "small-K layout");
+    constexpr int SB = SP::SB, DW = SP::DW, SPS = SP::SPS;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
-    constexpr int NBUF = 8;
-    constexpr int OUT_PAR = (SB >> 2) & 1, OUT_SIDX = SB & 3;  // byte complete when (group & 1) == OUT_PAR and step%4 == OUT_SIDX
+    constexpr int NBUF = 32 / SPS;                             // a window of the ring = 32 trellis steps = 4 output bytes
 
     const int lane = threadIdx.x & 63;
     const u32 f_raw = blockIdx.x * 64 + lane;
@@ -977,34 +979,37 @@ VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
     const u32 hshift = 8u * half;
 
     u32 reg = (a.end_state ? (a.end_state[f] & SP::SMASK) : 0u) << SHIFT_STATE;
-    auto chase = [&](u32 w, u32 ph1) __attribute__((always_inline)) {
+    auto chase = [&](u32 w0, u32 w1, u32 ph1) __attribute__((always_inline)) {
         const u32 state = reg >> SHIFT_STATE;
         const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot (= register) of `state` after step t
-        const u32 bit = (w >> ((x & 7u) + hshift + 16u * ((x >> 3) & 1u))) & 1u;  // SP::dec_bit(x, half)
+        const u32 w = (DW == 2 && (x & 16u)) ? w1 : w0;                       // decision dword = register / 16
+        const u32 bit = (w >> ((x & 7u) + hshift + 16u * ((x >> 3) & 1u))) & 1u;  // SP::dec_bit(x & 15, half)
         reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
     };
     auto slow_step = [&](int t) __attribute__((always_inline)) {
-        const u32* r32 = (const u32*)(rows + (size_t)(t >> 2) * 64) + (t & 3);
-        chase(r32[0], (u32)((t + 1) % SB));
+        const u32* r32 = (const u32*)(rows + (size_t)(t / SPS) * 64) + (t % SPS) * DW;
+        chase(r32[0], DW == 2 ? r32[DW - 1] : 0u, (u32)((t + 1) % SB));
         const int j = t - SB;
         if ((j & 7) == 0) out[(u32)j >> 3] = (uint8_t)((reg >> SHIFT_TAIL) & 0xFFu);
     };
 
     int t = (int)a.L - 1 + SB;
-    while (t >= SB && (((t & 3) != 3) || (((t >> 2) & 1) != 0))) slow_step(t--);   // to an even group boundary
-    const int g_top = t >> 2;
-    const int g_min = (SB + 3) / 4;
+    while (t >= SB && (t & 7) != 3) slow_step(t--);             // windows start at t = 3 (mod 8): the last step of a row
+    const int g_top = t / SPS;
+    const int g_min = (SB + SPS - 1) / SPS;                      // lowest row all of whose steps are >= SB
     if (t >= SB && g_top - (NBUF - 1) >= g_min) {
         uint4 buf[NBUF];
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(g_top - b) * 64];
         int gb = g_top;
-        u32 ph = (u32)((4 * gb + 3 + 1) % SB);
+        u32 ph = (u32)((SPS * gb + SPS - 1 + 1) % SB);
         // as in reg_chainback16_body: no store inside the ring loop (it would force vmcnt(0) at every loop top); the 4 bytes
-        // of an iteration are assembled in a register, parked in LDS and flushed as one dword store every KI iterations
+        // of a window are assembled in a register, parked in LDS and flushed as one dword store every KI windows
         constexpr int KI = 32;
         __shared__ u32 obuf[KI * 64];
         typedef u32 u32_unaligned __attribute__((aligned(1)));
+        // window step k (0..31, descending t = t_top - k, t_top = 3 mod 8) completes byte (t - SB) / 8 iff (3 - k - SB) % 8 == 0
+        constexpr int K_LAST = 24 + (((3 - SB) % 8) + 8) % 8;   // the last of the window's four such steps
         while (gb - (NBUF - 1) >= g_min) {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): retire the previous flush (and the ring)
             const int gb0 = gb;
@@ -1014,30 +1019,30 @@ VIT_DEV void reg_chainback0_body(const RegChainbackArgs& a) {
 #pragma unroll
                 for (int b = 0; b < NBUF; ++b) {
 #pragma unroll
-                    for (int sidx = 3; sidx >= 0; --sidx) {
-                        const u32 w = sidx == 0 ? buf[b].x : sidx == 1 ? buf[b].y : sidx == 2 ? buf[b].z : buf[b].w;
-                        chase(w, ph);
+                    for (int sidx = SPS - 1; sidx >= 0; --sidx) {
+                        const int k = b * SPS + (SPS - 1 - sidx);
+                        const int c0 = sidx * DW, c1 = sidx * DW + DW - 1;
+                        const u32 w0 = c0 == 0 ? buf[b].x : c0 == 1 ? buf[b].y : c0 == 2 ? buf[b].z : buf[b].w;
+                        const u32 w1 = c1 == 0 ? buf[b].x : c1 == 1 ? buf[b].y : c1 == 2 ? buf[b].z : buf[b].w;
+                        chase(w0, w1, ph);
                         ph = ph == 0 ? SB - 1 : ph - 1;
-                        // byte (4*grp + sidx - SB)/8 is complete; bytes come out in descending order
-                        if ((b & 1) == OUT_PAR && sidx == OUT_SIDX) acc = (acc << 8) | ((reg >> SHIFT_TAIL) & 0xFFu);
+                        // bytes come out in descending order
+                        if ((((3 - k - SB) % 8) + 8) % 8 == 0) acc = (acc << 8) | ((reg >> SHIFT_TAIL) & 0xFFu);
                     }
-                    asm volatile("" : "+v"(reg) : : "memory");   // pin the chase of this group in front of its refill
+                    asm volatile("" : "+v"(reg) : : "memory");   // pin the chase of this row in front of its refill
                     const int nxt = gb - b - NBUF;
                     buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 obuf[it * 64 + lane] = acc;
             }
-            // iteration i started at group G = gb0 - NBUF*i (even); its LAST completed byte is that of the lowest group with
-            // parity OUT_PAR: grp = G - 7 + ((OUT_PAR + 1) & 1) ... computed directly from the emit rule below
             for (int i = 0; i < it; ++i) {
-                const int G = gb0 - NBUF * i;
-                const int grp_last = G - (NBUF - 1) + ((OUT_PAR ^ 1) & 1);       // lowest group of the iteration with (b & 1) == OUT_PAR
-                const u32 jb = (u32)(4 * grp_last + OUT_SIDX - SB) >> 3;         // lowest of the 4 bytes
+                const int t_top = SPS * (gb0 - NBUF * i) + SPS - 1;
+                const u32 jb = (u32)(t_top - K_LAST - SB) >> 3;                 // lowest of the window's 4 bytes
                 *(u32_unaligned*)(out + jb) = obuf[i * 64 + lane];
             }
         }
-        t = 4 * gb + 3;
+        t = SPS * gb + SPS - 1;
     }
     while (t >= SB) slow_step(t--);
 }
@@ -1145,9 +1150,16 @@ inline bool reg_code_init(RegCode* rc, int K, int R, const uint32_t* G, const De
     return false;
 }
 
+// host mirror of RegSpec's geometry: lane bits, registers per lane, decision dwords per step, steps per 16-byte row
+inline int reg_lane_bits(int K) { return K >= 7 ? 2 : 0; }
+inline size_t reg_steps_per_row(int K) {
+    const size_t nreg = (size_t)1 << (K - 1 - reg_lane_bits(K));
+    const size_t dw = nreg >= 16 ? nreg / 16 : 1;
+    return 4 / dw;
+}
 inline size_t reg_groups(const RegCode& rc, size_t L) {
     const size_t S = L + (size_t)rc.K - 1;
-    const size_t sps = rc.K == 9 ? 1 : 4;
+    const size_t sps = reg_steps_per_row(rc.K);
     return (S + sps - 1) / sps;
 }
 inline size_t reg_tiles(const RegCode& rc, size_t frames) { return (frames + (size_t)rc.tile - 1) / (size_t)rc.tile; }
@@ -1296,7 +1308,7 @@ inline int reg_export(const RegCode& rc, const void* d_ws, size_t frames, size_t
     a.out = d_out;
     a.frames = (u32)frames;
     a.n_steps = (u32)n_steps;
-    const size_t W = rc.K == 9 ? 4 : 1;
+    const size_t W = rc.K >= 7 ? (size_t)1 << (rc.K - 7) : 1;
     const size_t total = frames * n_steps * W;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (rc.jit) return reg_jit_launch(rc.jit->export_, &a, sizeof(a), blocks, 256, st);
