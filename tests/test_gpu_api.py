@@ -23,8 +23,8 @@ def test_plan_selection_and_errors():
         info = dec._handle.info
         assert list(info.polynomials[:COMMON_CODES[cid].R]) == list(COMMON_CODES[cid].G) and info.table_is_linear == 1
         assert (info.soft_decision_high, info.soft_decision_low) == (127, -127)
-    # K=8 has no register plan (and no LDS2): served by the LDS plan, the others refused
-    code = Code("custom", 8, 2, (0o371, 0o247))
+    # K=10 has no register plan (and no LDS2): served by the LDS plan, the others refused
+    code = Code("custom", 10, 2, (0o1755, 0o1363))
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_LDS
@@ -145,6 +145,8 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     (3, 4, (0o5, 0o7, 0o7, 0o5), "HARD8"),
     (6, 2, (0o65, 0o57), "SOFT16"),          # K = 6: 32 states per lane, two decision dwords per step (round 2)
     (6, 4, (0o65, 0o57, 0o75, 0o53), "HARD8"),
+    (8, 2, (0o371, 0o247), "SOFT16"),        # K = 8: 32 registers per lane over 4 lanes, a decision row holds two steps
+    (8, 2, (0o371, 0o247), "SOFT8"),
 ])
 def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     """polynomials outside the ahead-of-time table: PLAN_REG is compiled for them on first use (reg_jit.hpp) and must

@@ -242,7 +242,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
     // depth of the symbol register ring, in groups of 4 steps (a divisor of the block): 6 groups = 24 steps of load latency
     // hidden for K = 7 (+1 % alone and overlapped over 3 groups), 2 for K = 9 (a step is four times longer there)
-    constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : 2);
+    constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : (U / GROUP) % 2 == 0 ? 2 : (U / GROUP) % 7 == 0 ? 7 : 1);
     constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
     static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
     constexpr bool RDTAB = SB * NP <= 32;         // read indices per (phase, pattern) in registers; else per phase + one v_xor per read
@@ -722,14 +722,18 @@ struct RegChainbackArgs {
 
 template <class SP>
 VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
-    // K = 9 (64 registers, one 16-byte row per lane per step): the update kernel's lane roles.  Every q-lane extracts the
-    // candidate bit of its slice, a ds_bpermute fetches the one of the slice that owns the survivor's slot.  Rows are
-    // fetched NBUF steps ahead into a register ring; the main loop is branch-free so the ring keeps counted vmcnt waits.
-    static_assert(SP::DW == 4 && SP::SPS == 1 && SP::SB == 8 && SP::LANE_BITS == 2, "K = 9 layout");
-    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS;
+    // K = 9 (64 registers: one 16-byte row per lane per step) and K = 8 (32 registers: a row holds two steps): the update
+    // kernel's lane roles.  Every q-lane extracts the candidate bit of its slice, a ds_bpermute fetches the one of the slice
+    // that owns the survivor's slot.  Rows are fetched NBUF rows ahead into a register ring; the main loop is branch-free so
+    // the ring keeps counted vmcnt waits.
+    static_assert(SP::LANE_BITS == 2 && SP::DW * SP::SPS == 4 && SP::NREG >= 32, "K = 8, 9 layout");
+    constexpr int SB = SP::SB, NREG = SP::NREG, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
-    constexpr int NBUF = 16;                                   // multiple of SB = 8: bytes complete at fixed slots of the ring
+    constexpr int PASS = 16;                                   // trellis steps per pass over the ring = 2 output bytes
+    constexpr int NBUF = PASS / SPS;                           // rows in the ring
+    // pass step k (0..15, descending t = t_top - k with t_top = 7 mod 8) completes byte (t - SB) / 8 iff (7 - k - SB) % 8 == 0
+    constexpr int K0 = (((7 - SB) % 8) + 8) % 8;               // the first such step of a pass; the second is K0 + 8
 
     const int lane = threadIdx.x & 63;
     const u32 g = lane & 15, q = lane >> 4;
@@ -737,7 +741,7 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     const u32 fA_raw = (u32)tile * 32 + g, fB_raw = fA_raw + 16;
     const bool validA = fA_raw < a.frames, validB = fB_raw < a.frames;
     const u32 fA = validA ? fA_raw : a.frames - 1, fB = validB ? fB_raw : a.frames - 1;   // surplus lanes: identical stores
-    const uint4* rows = a.ws + tile * a.ws_tile_stride + lane;      // row of step t = rows[t*64]
+    const uint4* rows = a.ws + tile * a.ws_tile_stride + lane;      // row of step t = rows[(t / SPS) * 64]
     const size_t out_stride = ((size_t)a.L + 7) / 8;
     uint8_t* outA = a.out + (size_t)fA * out_stride;
     uint8_t* outB = a.out + (size_t)fB * out_stride;
@@ -745,11 +749,12 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     u32 regA = (a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u) << SHIFT_STATE;
     u32 regB = (a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u) << SHIFT_STATE;
 
-    auto trace = [&](u32& reg, const uint4& v, u32 half, u32 ph1) __attribute__((always_inline)) {
+    // `sub`: which of the row's SPS steps (compile time in the ring, run time in the ragged ends)
+    auto trace = [&](u32& reg, const uint4& v, u32 half, u32 ph1, u32 sub) __attribute__((always_inline)) {
         const u32 state = reg >> SHIFT_STATE;
         const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
         const u32 qs = x >> REG_BITS, rs = x & (NREG - 1);
-        const u32 d = rs >> 4;                                                // dword = slot register / 16
+        const u32 d = sub * DW + (rs >> 4);                                   // dword = step within the row, slot register / 16
         const u32 w = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
         const u32 mine = (w >> SP::dec_bit(rs, half)) & 1u;                  // candidate from this lane's slice
         const u32 bit = (u32)__shfl((int)mine, (int)(qs * 16 + g));          // the slice that owns slot x
@@ -762,56 +767,60 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
         }
     };
     auto slow_step = [&](int t) __attribute__((always_inline)) {
-        const uint4 v = rows[(size_t)t * 64];
+        const uint4 v = rows[(size_t)(t / SPS) * 64];
         const u32 ph1 = (u32)((t + 1) % SB);
-        trace(regA, v, 0u, ph1);
-        trace(regB, v, 1u, ph1);
+        trace(regA, v, 0u, ph1, (u32)(t % SPS));
+        trace(regB, v, 1u, ph1, (u32)(t % SPS));
         const int j = t - SB;
         if ((j & 7) == 0) emit((u32)j >> 3);
     };
 
     int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
-    while (t >= SB && (t & 7) != 7) slow_step(t--);             // down to a multiple-of-8 boundary
-    if (t >= SB && t - (NBUF - 1) >= SB) {
+    while (t >= SB && (t & 7) != 7) slow_step(t--);             // down to a multiple-of-8 boundary (the last step of a row)
+    if (t >= SB && t - (PASS - 1) >= SB) {
         uint4 buf[NBUF];
 #pragma unroll
-        for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(t - b) * 64];
-        // One pass over the ring = NBUF steps = NBUF/8 output bytes per frame.  Inside the inner loop ONLY loads are
-        // outstanding (see reg_chainback16_body: a pending store makes hipcc drain the ring with vmcnt(0) at every loop top):
-        // the bytes are parked in LDS, [dword][lane][byte] so that neither the byte writes nor the dword reads of the flush
-        // conflict, and flushed as (possibly unaligned) dword stores every KI passes.
-        constexpr int BPP = NBUF / 8;                            // bytes per frame and pass
+        for (int b = 0; b < NBUF; ++b) buf[b] = rows[(size_t)(t / SPS - b) * 64];
+        // One pass over the ring = 16 steps = 2 output bytes per frame.  Inside the inner loop ONLY loads are outstanding
+        // (see reg_chainback16_body: a pending store makes hipcc drain the ring with vmcnt(0) at every loop top): the bytes
+        // are parked in LDS, [dword][lane][byte] so that neither the byte writes nor the dword reads of the flush conflict,
+        // and flushed as (possibly unaligned) dword stores every KI passes.
+        constexpr int BPP = PASS / 8;                            // bytes per frame and pass
         constexpr int KI = 128 / BPP;                            // 128 bytes per frame between flushes
         __shared__ u32 obufA[32 * 64], obufB[32 * 64];
         typedef u32 u32_unaligned __attribute__((aligned(1)));
-        while (t - (NBUF - 1) >= SB) {
+        u32 ph_run = (u32)((t + 1) % SB);                        // (t + 1) % SB of the ring's top step; only used when SB != 8
+        while (t - (PASS - 1) >= SB) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): retire the previous flush (and the ring)
-            const int t_top = t;
             int it = 0;
-            for (; it < KI && t - (NBUF - 1) >= SB; ++it, t -= NBUF) {
+            for (; it < KI && t - (PASS - 1) >= SB; ++it, t -= PASS) {
 #pragma unroll
                 for (int b = 0; b < NBUF; ++b) {
-                    // step t-b with t % 8 == 7: (t - b + 1) % 8 == (8 - b) % 8
-                    const u32 ph1 = (u32)((8 - (b % 8)) % 8);
-                    trace(regA, buf[b], 0u, ph1);
-                    trace(regB, buf[b], 1u, ph1);
-                    if (b % 8 == 7) {
-                        // j = t-b-8 is a multiple of 8: byte (t-b-8)/8 is complete; slot counts down from the top of the flush
-                        const int slot = 127 - (it * BPP + b / 8);
-                        ((uint8_t*)obufA)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
-                        ((uint8_t*)obufB)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+#pragma unroll
+                    for (int sidx = SPS - 1; sidx >= 0; --sidx) {
+                        const int k = b * SPS + (SPS - 1 - sidx);
+                        // step t - k with t % 8 == 7: for SB == 8 the phase (t - k + 1) % 8 is a compile-time constant
+                        const u32 ph1 = SB == 8 ? (u32)((8 - (k % 8)) % 8) : ph_run;
+                        trace(regA, buf[b], 0u, ph1, (u32)sidx);
+                        trace(regB, buf[b], 1u, ph1, (u32)sidx);
+                        if (SB != 8) ph_run = ph_run == 0 ? SB - 1 : ph_run - 1;
+                        if (k % 8 == K0) {
+                            // byte (t - k - SB) / 8 is complete; slot counts down from the top of the flush
+                            const int slot = 127 - (it * BPP + k / 8);
+                            ((uint8_t*)obufA)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
+                            ((uint8_t*)obufB)[(slot >> 2) * 256 + lane * 4 + (slot & 3)] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+                        }
                     }
                     asm volatile("" : "+v"(regA), "+v"(regB) : : "memory");   // pin the chase in front of the refill
-                    const int nxt = t - b - NBUF;
+                    const int nxt = t / SPS - b - NBUF;
                     buf[b] = rows[(size_t)(nxt < 0 ? 0 : nxt) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // the passes completed bytes (t_top - 7 - SB)/8 down to (t + 1 - SB)/8 = slots 127 down to 128 - it*BPP
+            // the passes completed slots 127 down to 128 - it*BPP; the lowest of them is the byte of step t + PASS - (K0 + 8)
             if (q == 0) {
                 const int nbytes = it * BPP;
-                const u32 jb_lo = (u32)(t + 1 - SB) >> 3;        // byte index of slot 128 - nbytes
-                (void)t_top;
+                const u32 jb_lo = (u32)(t + PASS - (K0 + 8) - SB) >> 3;    // byte index of slot 128 - nbytes
                 int sl = 128 - nbytes;
                 // leading bytes up to a dword boundary of the slot space, then whole dwords
                 for (; (sl & 3) != 0 && sl < 128; ++sl) {

@@ -38,6 +38,7 @@ namespace vit {
 // which only stays reasonable (<= 40) for R = 2 and R = 4
 inline bool reg_jit_supported(int K, int R) {
     if (K == 6) return R == 2 || R == 4;
+    if (K == 8) return R == 1 || R == 2;      // the 28-step block of 7 state bits only keeps its LDS ring whole for <= 4 patterns
     return (K == 3 || K == 4 || K == 5 || K == 7 || K == 9) && R >= 1 && R <= 4;
 }
 
@@ -135,7 +136,7 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 // returns nullptr and fills `err` on failure.  The module belongs to the current device.
 inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int device, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5,7,9} with R <= 4 and K = 6 with R = 2 or 4"; return nullptr; }
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5,7,9} with R <= 4, K = 6 with R = 2 or 4, K = 8 with R <= 2"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");
