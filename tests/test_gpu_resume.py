@@ -25,6 +25,11 @@ CASES = [
     (COMMON_CODES[7], "SOFT16", _lib.PLAN_LDS2, 3, 40),       # K15
     (Code("K16 R=1/2", 16, 2, (46749, 58851)), "SOFT16", _lib.PLAN_LDS2, 3, 24),
     (K6, "SOFT16", _lib.PLAN_LDS, 4, 88),
+    # run-time compiled register-plan instantiations carry their own resume kernels (same polynomials as tests/test_gpu_api.py:
+    # the code objects come from the on-disk cache when that file ran first)
+    (Code("custom K7", 7, 2, (0o171, 0o133)), "SOFT16", _lib.PLAN_REG, 40, 200),
+    (K6, "SOFT16", _lib.PLAN_REG, 70, 104),
+    (Code("custom K8", 8, 2, (0o371, 0o247)), "SOFT8", _lib.PLAN_REG, 37, 120),
     (COMMON_CODES[2], "SOFT16", _lib.PLAN_LDS, 3, 88),
 ]
 
