@@ -13,6 +13,8 @@
  *   vit_hip_update_batch      reset() + Decoder::update<sum_t>()  viterbi_decoder_core.h:202-211, viterbi_decoder_scalar.h:29-55
  *   vit_hip_chainback_batch   chainback()                         viterbi_decoder_core.h:214-236
  *   vit_hip_decode_batch      the call pattern reset->update->chainback of examples/run_simple.cpp:76-80
+ *   vit_hip_pipeline_*        the same pattern over a stream of batches, the two phases timed separately by the reference
+ *                             (examples/run_benchmark.cpp:272-281) overlapped on two HIP streams
  *   vit_hip_update_host       update() on a host-resident Core (streaming, N = R allowed:
  *                                                                 examples/helpers/puncture_code_helpers.h:51)
  *   vit_hip_chainback_host    chainback() on host-resident decision rows
@@ -146,6 +148,20 @@ int vit_hip_export_decisions(vit_hip_handle h, const void* d_workspace, size_t f
 int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t punctured_per_frame,
                              const int32_t* d_source_index, size_t symbols_per_frame, size_t frames, void* d_symbols_out,
                              vit_hip_stream_t stream);
+
+/* ---- double-buffered decode pipeline --------------------------------------------------------------------------------- */
+
+/* update() is bound by integer issue, chainback() by memory latency: run back to back they leave each other's resource
+ * idle.  A pipeline owns two decision workspaces and two HIP streams and runs the chainback of batch i beside the update of
+ * batch i+1 (the schedule bench.py measures: K = 7 soft16 4.15 -> 3.46 ms per 65536-frame batch).  submit() only enqueues
+ * and returns; batches complete in order; the caller's symbol and output buffers of a batch must stay untouched until a
+ * later sync() (or until `done_event`, an optional hipEvent_t passed as void*, has fired). */
+typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
+int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
+int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, void* done_event);
+int vit_hip_pipeline_sync(vit_hip_pipeline_t p);
+int vit_hip_pipeline_destroy(vit_hip_pipeline_t p);
 
 /* ---- batched streaming: a batch of decoders fed in chunks, state resident on the device ------------------------- */
 

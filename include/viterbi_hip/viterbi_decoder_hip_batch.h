@@ -101,3 +101,31 @@ private:
     }
     vit_hip_handle m_hip = nullptr;
 };
+
+// Double-buffered pipeline over a batch decoder (vit_hip_pipeline_*): chainback of batch i runs beside the update of batch
+// i+1 on a second stream.  submit() only enqueues; results of a batch are valid after a later sync().
+template <size_t constraint_length, size_t code_rate, typename error_t, typename soft_t>
+class ViterbiDecoder_HIP_Pipeline {
+public:
+    using Batch = ViterbiDecoder_HIP_Batch<constraint_length, code_rate, error_t, soft_t>;
+    ViterbiDecoder_HIP_Pipeline(Batch& decoder, size_t max_frames, size_t total_bits) {
+        if (vit_hip_pipeline_create(decoder.hip_handle(), max_frames, total_bits, &m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_create");
+    }
+    ~ViterbiDecoder_HIP_Pipeline() { vit_hip_pipeline_destroy(m_pipe); }
+    ViterbiDecoder_HIP_Pipeline(const ViterbiDecoder_HIP_Pipeline&) = delete;
+    ViterbiDecoder_HIP_Pipeline& operator=(const ViterbiDecoder_HIP_Pipeline&) = delete;
+    void submit(const soft_t* d_symbols, size_t frames, uint8_t* d_bytes_out, const uint32_t* d_end_state = nullptr,
+                void* done_event = nullptr) {
+        if (vit_hip_pipeline_submit(m_pipe, d_symbols, frames, d_bytes_out, d_end_state, done_event) != VIT_HIP_OK) die("vit_hip_pipeline_submit");
+    }
+    void sync() {
+        if (vit_hip_pipeline_sync(m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_sync");
+    }
+
+private:
+    static void die(const char* what) {
+        fprintf(stderr, "viterbi_hip: %s failed: %s\n", what, vit_hip_last_error());
+        abort();
+    }
+    vit_hip_pipeline_t m_pipe = nullptr;
+};

@@ -201,3 +201,33 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
         for plan in plans:
             dec = BatchDecoder(table, config, plan=plan)
             assert np.array_equal(dec.decode(view, L).cpu().numpy(), want), (off, plan)
+
+
+def test_decode_pipeline_matches_serial_decode():
+    """vit_hip_pipeline_*: the double-buffered schedule (chainback of batch i beside the update of batch i+1) returns the
+    bytes of the serial vit_hip_decode_batch for every batch, including batches smaller than the pipeline's maximum."""
+    import ctypes as C
+    import torch
+
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    lib = _lib.load()
+    F, L = 2048, 1024
+    pipe = C.c_void_p()
+    assert lib.vit_hip_pipeline_create(dec._handle._h, F, L, C.byref(pipe)) == _lib.OK
+    batches, outs = [], []
+    for k in range(5):
+        n = F if k != 3 else 777
+        tx, sym = dec.synth(n, L, 2.0, seed=50 + k)
+        out = torch.zeros((n, L // 8), dtype=torch.uint8, device="cuda")
+        batches.append((n, sym, tx))
+        outs.append(out)
+    torch.cuda.synchronize()
+    for (n, sym, _), out in zip(batches, outs):
+        assert lib.vit_hip_pipeline_submit(pipe, C.c_void_p(sym.data_ptr()), n, C.c_void_p(out.data_ptr()), None, None) == _lib.OK
+    assert lib.vit_hip_pipeline_submit(pipe, C.c_void_p(batches[0][1].data_ptr()), F + 1, C.c_void_p(outs[0].data_ptr()), None, None) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_pipeline_sync(pipe) == _lib.OK
+    for (n, sym, tx), out in zip(batches, outs):
+        assert torch.equal(out, dec.decode(sym, L))
+    assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK

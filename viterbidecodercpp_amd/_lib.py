@@ -24,7 +24,8 @@ EXPORTS = [
     "vit_hip_workspace_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
     "vit_hip_export_decisions", "vit_hip_depuncture_batch", "vit_hip_update_host", "vit_hip_chainback_host",
     "vit_hip_reset_batch", "vit_hip_update_batch_resume", "vit_hip_broadcast_table", "vit_hip_synth_batch",
-    "vit_hip_count_bit_errors",
+    "vit_hip_count_bit_errors", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
+    "vit_hip_pipeline_destroy",
 ]
 
 
@@ -80,6 +81,10 @@ def load():
     L.vit_hip_broadcast_table.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     L.vit_hip_synth_batch.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, C.c_float, i32, vp, vp, vp]
     L.vit_hip_count_bit_errors.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.vit_hip_pipeline_create.argtypes = [vp, sz, sz, C.POINTER(vp)]
+    L.vit_hip_pipeline_submit.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.vit_hip_pipeline_sync.argtypes = [vp]
+    L.vit_hip_pipeline_destroy.argtypes = [vp]
     L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     L.vit_hip_chainback_host.argtypes = [vp, vp, sz, sz, vp]
     _lib = L

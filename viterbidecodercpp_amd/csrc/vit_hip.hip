@@ -9,6 +9,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <new>
 #include <string>
 #include <vector>
 
@@ -589,6 +590,94 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
         hipLaunchKernelGGL(vit::depuncture_kernel<int8_t>, dim3(blocks), dim3(256), 0, st, (const int8_t*)d_punctured,
                            punctured_per_frame, d_source_index, symbols_per_frame, frames, (int8_t*)d_symbols_out);
     VIT_HIP_CHECK(hipGetLastError());
+    return VIT_HIP_OK;
+}
+
+}  // extern "C"
+
+struct vit_hip_pipeline {
+    vit_hip_handle h = nullptr;
+    size_t max_frames = 0, L = 0, ws_bytes = 0;
+    void* ws[2] = {nullptr, nullptr};
+    hipStream_t s_upd = nullptr, s_cb = nullptr;
+    hipEvent_t upd_done[2] = {nullptr, nullptr}, cb_done[2] = {nullptr, nullptr};
+    bool cb_pending[2] = {false, false};
+    unsigned long long n = 0;
+};
+
+extern "C" {
+
+int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
+    if (!h || !out || max_frames == 0) return fail(VIT_HIP_ERR_INVALID_ARG, "bad pipeline arguments");
+    *out = nullptr;
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    vit_hip_pipeline* p = new (std::nothrow) vit_hip_pipeline();
+    if (!p) return fail(VIT_HIP_ERR_RUNTIME, "out of host memory");
+    p->h = h; p->max_frames = max_frames; p->L = L;
+    p->ws_bytes = vit_hip_workspace_bytes(h, max_frames, L);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
+    bool ok = hipStreamCreateWithFlags(&p->s_upd, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithPriority(&p->s_cb, hipStreamNonBlocking, hi) == hipSuccess;   // the short bit chase gets out of the update's way
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipMalloc(&p->ws[k], p->ws_bytes) == hipSuccess &&
+             hipEventCreateWithFlags(&p->upd_done[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p->cb_done[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)vit_hip_pipeline_destroy(p);
+        return fail(VIT_HIP_ERR_RUNTIME, "pipeline allocation failed (two decision workspaces of vit_hip_workspace_bytes each)");
+    }
+    *out = p;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, void* done_event) {
+    if (!p) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL pipeline");
+    if (frames > p->max_frames) return fail(VIT_HIP_ERR_INVALID_ARG, "batch larger than the pipeline was created for");
+    if (frames == 0) return VIT_HIP_OK;
+    DeviceGuard guard(p->h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    const int k = (int)(p->n & 1ull);
+    // the chainback that last read this workspace must have finished before the update overwrites it
+    if (p->cb_pending[k]) VIT_HIP_CHECK(hipStreamWaitEvent(p->s_upd, p->cb_done[k], 0));
+    int rc = vit_hip_update_batch(p->h, d_symbols, frames, p->L + (size_t)p->h->K - 1, p->L, p->ws[k], p->ws_bytes, nullptr, nullptr,
+                                  nullptr, p->s_upd);
+    if (rc != VIT_HIP_OK) return rc;
+    VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], p->s_upd));
+    VIT_HIP_CHECK(hipStreamWaitEvent(p->s_cb, p->upd_done[k], 0));
+    rc = vit_hip_chainback_batch(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, p->s_cb);
+    if (rc != VIT_HIP_OK) return rc;
+    VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], p->s_cb));
+    if (done_event) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, p->s_cb));
+    p->cb_pending[k] = true;
+    p->n++;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_sync(vit_hip_pipeline_t p) {
+    if (!p) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL pipeline");
+    DeviceGuard guard(p->h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    VIT_HIP_CHECK(hipStreamSynchronize(p->s_upd));
+    VIT_HIP_CHECK(hipStreamSynchronize(p->s_cb));
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_destroy(vit_hip_pipeline_t p) {
+    if (!p) return VIT_HIP_OK;
+    DeviceGuard guard(p->h->device);
+    if (p->s_upd) (void)hipStreamSynchronize(p->s_upd);
+    if (p->s_cb) (void)hipStreamSynchronize(p->s_cb);
+    for (int k = 0; k < 2; ++k) {
+        if (p->ws[k]) (void)hipFree(p->ws[k]);
+        if (p->upd_done[k]) (void)hipEventDestroy(p->upd_done[k]);
+        if (p->cb_done[k]) (void)hipEventDestroy(p->cb_done[k]);
+    }
+    if (p->s_upd) (void)hipStreamDestroy(p->s_upd);
+    if (p->s_cb) (void)hipStreamDestroy(p->s_cb);
+    delete p;
     return VIT_HIP_OK;
 }
 
