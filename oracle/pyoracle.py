@@ -103,6 +103,10 @@ class Oracle:
         L.vo_encode.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.vo_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_decode_frames_hashed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vo_hash_decisions.argtypes = [C.c_void_p, C.c_size_t]
+        L.vo_hash_decisions.restype = C.c_uint64
 
     @staticmethod
     def params(K, R, cfg: DecodeConfig):
@@ -167,8 +171,16 @@ class Oracle:
         out = self.chainback(K, dec, L, end_state) if n_steps >= L + K - 1 else None
         return dict(decisions=dec, metrics=m.copy(), renorm_sum=rs, error=int(m[end_state]), bytes=out)
 
-    def decode_frames(self, K, R, G, cfg, symbols, L, threads=1, want_metrics=False):
-        """[F][S][R] symbols -> (bytes [F][L/8], metrics [F][N] or None, renorm [F])."""
+    HASH_MUL = 0x9E3779B97F4A7C15
+
+    def hash_decisions(self, words: np.ndarray) -> int:
+        """vo_hash_decisions of one frame's [S][W] uint64 history."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        return int(self.lib.vo_hash_decisions(_ptr(words), words.size))
+
+    def decode_frames(self, K, R, G, cfg, symbols, L, threads=1, want_metrics=False, want_hash=False):
+        """[F][S][R] symbols -> (bytes [F][L/8], metrics [F][N] or None, renorm [F]); with want_hash a fourth array: the
+        64-bit digest of every decision word of each frame (viterbi_oracle.h: vo_decode_frames_hashed)."""
         symbols = np.ascontiguousarray(symbols, dtype=cfg.soft_dtype)
         S = L + K - 1
         F = symbols.size // (S * R)
@@ -178,6 +190,11 @@ class Oracle:
         met = np.zeros((F, 1 << (K - 1)), dtype=np.uint32) if want_metrics else None
         rs = np.zeros(F, dtype=np.uint64)
         p = self.params(K, R, cfg)
+        if want_hash:
+            hs = np.zeros(F, dtype=np.uint64)
+            self.lib.vo_decode_frames_hashed(C.byref(p), _ptr(table), _ptr(symbols), F, L, _ptr(out), _ptr(met), _ptr(rs),
+                                             _ptr(hs), threads)
+            return out, met, rs, hs
         self.lib.vo_decode_frames(C.byref(p), _ptr(table), _ptr(symbols), F, L, _ptr(out), _ptr(met), _ptr(rs), threads)
         return out, met, rs
 

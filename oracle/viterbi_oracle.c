@@ -176,7 +176,14 @@ typedef struct {
     uint8_t* bytes_out;
     uint32_t* final_metrics;
     uint64_t* renorm_sum;
+    uint64_t* decision_hash;
 } vo_job;
+
+uint64_t vo_hash_decisions(const uint64_t* words, size_t n) {
+    uint64_t h = 0;
+    for (size_t i = 0; i < n; i++) h += words[i] * ((2u * (uint64_t)i + 1u) * VO_HASH_MUL);
+    return h;
+}
 
 static void* vo_worker(void* arg) {
     vo_job* j = (vo_job*)arg;
@@ -192,6 +199,7 @@ static void* vo_worker(void* arg) {
         vo_chainback(p->K, dec, j->L, 0, j->bytes_out + f * ((j->L + 7) / 8));
         if (j->final_metrics) memcpy(j->final_metrics + f * N, m, N * sizeof(uint32_t));
         if (j->renorm_sum) j->renorm_sum[f] = rs;
+        if (j->decision_hash) j->decision_hash[f] = vo_hash_decisions(dec, S * W);
     }
     free(dec);
     free(m);
@@ -200,6 +208,12 @@ static void* vo_worker(void* arg) {
 
 int vo_decode_frames(const vo_params* p, const int16_t* table, const void* symbols, size_t frames, size_t L,
                      uint8_t* bytes_out, uint32_t* final_metrics, uint64_t* renorm_sum, int threads) {
+    return vo_decode_frames_hashed(p, table, symbols, frames, L, bytes_out, final_metrics, renorm_sum, NULL, threads);
+}
+
+int vo_decode_frames_hashed(const vo_params* p, const int16_t* table, const void* symbols, size_t frames, size_t L,
+                            uint8_t* bytes_out, uint32_t* final_metrics, uint64_t* renorm_sum, uint64_t* decision_hash,
+                            int threads) {
     if (threads < 1) threads = 1;
     if ((size_t)threads > frames) threads = frames ? (int)frames : 1;
     pthread_t* th = (pthread_t*)malloc((size_t)threads * sizeof(pthread_t));
@@ -214,6 +228,7 @@ int vo_decode_frames(const vo_params* p, const int16_t* table, const void* symbo
         jobs[t].bytes_out = bytes_out;
         jobs[t].final_metrics = final_metrics;
         jobs[t].renorm_sum = renorm_sum;
+        jobs[t].decision_hash = decision_hash;
         if (threads == 1)
             vo_worker(&jobs[t]);
         else

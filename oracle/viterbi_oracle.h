@@ -69,6 +69,16 @@ void vo_encode(int K, int R, const uint32_t* G, const uint8_t* bytes, size_t n_b
 int vo_decode_frames(const vo_params* p, const int16_t* table, const void* symbols, size_t frames, size_t L,
                      uint8_t* bytes_out, uint32_t* final_metrics, uint64_t* renorm_sum, int threads);
 
+/* The same, plus a 64-bit digest of every decision word of each frame (decision_hash [F], may be NULL), so that a whole
+ * full-size batch can be compared word for word without keeping 4-70 GB of decision rows on the host:
+ *   hash = sum_i words[i] * ((2 i + 1) * VO_HASH_MUL)  mod 2^64,  i = t * W + w over the frame's [S][W] history.
+ * Every multiplier is odd, so a change of any single word changes the digest. */
+#define VO_HASH_MUL 0x9E3779B97F4A7C15ull
+uint64_t vo_hash_decisions(const uint64_t* words, size_t n);
+int vo_decode_frames_hashed(const vo_params* p, const int16_t* table, const void* symbols, size_t frames, size_t L,
+                            uint8_t* bytes_out, uint32_t* final_metrics, uint64_t* renorm_sum, uint64_t* decision_hash,
+                            int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,15 @@ def test_oracle_frames_driver_threads(oracle):
     a, ma, ra = oracle.decode_frames(code.K, code.R, code.G, cfg, sym, 256, threads=1, want_metrics=True)
     b, mb, rb = oracle.decode_frames(code.K, code.R, code.G, cfg, sym, 256, threads=4, want_metrics=True)
     assert np.array_equal(a, b) and np.array_equal(ma, mb) and np.array_equal(ra, rb)
+    *_, ha = oracle.decode_frames(code.K, code.R, code.G, cfg, sym, 256, threads=3, want_hash=True)
     for f in range(9):
         one = oracle.decode(code.K, code.R, code.G, cfg, sym[f], 256)
         assert np.array_equal(one["bytes"], a[f]) and one["renorm_sum"] == int(ra[f])
+        # the per-frame digest of the decision words (vo_decode_frames_hashed) restated in numpy
+        w = one["decisions"].reshape(-1)
+        with np.errstate(over="ignore"):
+            h = (w * ((2 * np.arange(w.size, dtype=np.uint64) + 1) * np.uint64(oracle.HASH_MUL))).sum(dtype=np.uint64)
+        assert int(ha[f]) == int(h) == oracle.hash_decisions(one["decisions"])
+        w2 = w.copy()
+        w2[17] ^= np.uint64(1) << np.uint64(40)     # any single flipped bit changes it (odd multipliers)
+        assert oracle.hash_decisions(w2) != int(h)
