@@ -170,6 +170,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     u32* const met = flag + 16;                                // [N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the step range, pinned uniform up front: read where it is needed, the compiler re-loads it on one side of a per-thread
+    // branch (tid == 0 ...) and merges the copies in a phi that counts as divergent -- and with it the block loop's counter,
+    // its table-set bit and every branch on them (vector compares, exec-mask branches, loop counters in VGPRs)
+    const u32 t_begin = (u32)__builtin_amdgcn_readfirstlane((int)a.t_begin), t_end = (u32)__builtin_amdgcn_readfirstlane((int)a.t_end);
     const u32 pair = blockIdx.x;
     const u32 fA = 2 * pair;
     const bool validB = fA + 1 < a.frames;
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     const uint8_t* symB = a.symbols + (size_t)fB * a.sym_frame_stride_bytes;
     auto load_syms = [&](u32 abs_step, u32 (&y)[6]) __attribute__((always_inline)) {
         // packed (frame A | frame B << 16) symbols of trellis step `abs_step` in the device's 16-bit domain
-        const u32 step = abs_step - a.t_begin;      // the chunk starts at step t_begin
+        const u32 step = abs_step - t_begin;      // the chunk starts at step t_begin
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin) load_syms(t0 + (u32)c, yland[i]);
+            if (c < BLK && t0 + (u32)c < t_end && t0 + (u32)c >= t_begin) load_syms(t0 + (u32)c, yland[i]);
         }
     };
     auto tables_commit = [&]() __attribute__((always_inline)) {
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < a.t_end && t0 + (u32)c >= a.t_begin)
+            if (c < BLK && t0 + (u32)c < t_end && t0 + (u32)c >= t_begin)
                 build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], c == 0 ? xorB[0] : c == 1 ? xorB[1] : c == 2 ? xorB[2] : xorB[3],
                             tabpos[i]);
         }
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         u32 lo = m0 & 0xFFFFu, hi = m0 >> 16;
 #pragma unroll
         for (int c = 0; c < BLK - 1; ++c) {
-            if (t_next + (u32)c < a.t_end) {
+            if (t_next + (u32)c < t_end) {
                 const u32 e = etab[(size_t)(set * BLK + c) * GPT * 64].x;
                 lo += e & 0xFFFFu;
                 hi += e >> 16;
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         const u32 thr = a.cfg.threshold;
         return (lo >= thr || hi >= thr) ? 1u : 0u;      // threshold 0: always
     };
-    const u32 tb0 = a.t_begin & ~(u32)(BLK - 1);   // the block that holds step t_begin (0 for a fresh decode)
+    const u32 tb0 = t_begin & ~(u32)(BLK - 1);   // the block that holds step t_begin (0 for a fresh decode)
     tables_load(tb0);
     tables_commit();
     tables_build(tb0, 0);
@@ -450,7 +454,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     // the careful version of a block: stages [c_first, nst) with the threshold test and the reduction after EVERY stage; used
     // when the prediction says state 0 may cross the threshold inside the block, for the entry block of a resumed call
     // (c_first > 0) and for the last partial block of a frame (nst < BLK).  Returns the prediction for the next block.
-    auto slow_block = [&](u32 t0, int set, int c_first, int nst) __attribute__((always_inline)) -> bool {
+    auto slow_block = [&](u32 t0, int set, int c_first, int nst) __attribute__((always_inline)) -> u32 {
         tables_build(t0 + BLK, set ^ 1);       // nobody has built the next block's tables yet
         tables_load(t0 + 2 * BLK);
         tables_commit();
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
                 // state 0 is register 0 of thread 0's first group after every stage
                 if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
                 __syncthreads();
-                const u32 need = flag[2];
+                const u32 need = (u32)__builtin_amdgcn_readfirstlane((int)flag[2]);   // block-uniform: scalar branch
                 __syncthreads();
                 if (need != 0) renormalise(need);
                 if (C == nst - 1) {
@@ -494,10 +498,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         });
         if (tid == 0) flag[0] = nst == BLK ? predict(mA[0], t0 + BLK, set ^ 1) : 1u;
         __syncthreads();                       // B2
-        return flag[0] != 0;
+        return (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);
     };
     // the fast version: four stages back to back between the two barriers.  Returns the prediction for the next block.
-    auto fast_block = [&](int set, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> bool {
+    auto fast_block = [&](int set, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> u32 {
         // the metric loads go out first; behind them, while they are in flight: the tables of the NEXT block from the symbols
         // fetched during the previous one
         load_metrics();
@@ -516,9 +520,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         if (tid == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);
         __syncthreads();                       // B2
         tables_commit();
-        const bool pred = flag[0] != 0;
+        const u32 pred = (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);   // uniform by construction, and carried as a dword (a
+                                                                              // loop-carried bool becomes a lane mask): the block loop's control flow stays scalar
         // renormalise when new_metric[0] >= threshold after the block's last step: block-uniform
-        const u32 need = (l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2;   // sign bits: frame A / frame B
+        const u32 need = (u32)__builtin_amdgcn_readfirstlane((int)((l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2));   // sign bits: frame A / frame B
         if (need != 0) {
             __syncthreads();                   // everybody has read met[0] and flag[0] before they can change
             renormalise(need);
@@ -531,12 +536,12 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     u32 t0 = tb0;
     u32 arrivals_wanted = (u32)NW;            // value of *arrive once every wavefront has loaded the current block's metrics
     int set = 0;                              // table set that holds block t0
-    bool careful = flag[0] != 0;
-    while (t0 < a.t_end) {
-        const u32 left = a.t_end - t0;
+    u32 careful = (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);
+    while (t0 < t_end) {
+        const u32 left = t_end - t0;
         const int nst = left < (u32)BLK ? (int)left : BLK;
-        const int c_first = t0 < a.t_begin ? (int)(a.t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
-        if (nst < BLK || c_first > 0 || careful) careful = slow_block(t0, set, c_first, nst);
+        const int c_first = t0 < t_begin ? (int)(t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
+        if (nst < BLK || c_first > 0 || careful != 0) careful = slow_block(t0, set, c_first, nst);
         else careful = fast_block(set, t0, arrivals_wanted);
         // the next block reads the other table set: flip the set bit in all packed offsets
 #pragma unroll
