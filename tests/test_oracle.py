@@ -124,3 +124,21 @@ def test_oracle_frames_driver_threads(oracle):
         w2 = w.copy()
         w2[17] ^= np.uint64(1) << np.uint64(40)     # any single flipped bit changes it (odd multipliers)
         assert oracle.hash_decisions(w2) != int(h)
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """GPU sanitizers are not available on the pool; the checker itself at least runs clean under ASan + UBSan on the CPU:
+    204 random decoders (K = 2 ... 11, both widths, thresholds 0 / type-max, ragged L, chunked updates, the threaded driver)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.run([gcc, "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I" + os.path.join(root, "oracle"), "-o", exe, os.path.join(root, "tests", "cpp", "oracle_sanitize.c"),
+                    os.path.join(root, "oracle", "viterbi_oracle.c"), "-lpthread"], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout and "runtime error" not in r.stderr, r.stdout + r.stderr
