@@ -48,12 +48,6 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ uint32_t synth_info_byte(const SynthArgs& a, uint64_t frame, uint32_t i) {
-    uint32_t x[4];
-    philox4x32_10(i >> 4, (uint32_t)frame, 0u, (uint32_t)(frame >> 32), (uint32_t)a.seed, (uint32_t)(a.seed >> 32), x);
-    return (x[(i >> 2) & 3u] >> (8u * (i & 3u))) & 0xFFu;
-}
-
 template <typename soft_t, int R>
 __global__ void __launch_bounds__(256) synth_kernel(SynthArgs a) {
     const uint32_t nchunks = (a.S + 7u) / 8u;
@@ -94,7 +88,6 @@ __global__ void __launch_bounds__(256) synth_kernel(SynthArgs a) {
     float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        constexpr int dummy = 0; (void)dummy;
         const uint32_t s = (uint32_t)(k / R), i = (uint32_t)(k % R);
         const uint32_t reg = (word >> (7u - s)) & kmask;       // bit j = input bit of step t - j  (shift_register.h:47-58)
         const uint32_t bit = (uint32_t)__builtin_popcount(reg & a.G[i]) & 1u;
