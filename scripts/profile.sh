@@ -12,7 +12,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 STEPS=${PROFILE_STEPS:-20}
-ARGS="--steps $STEPS --warmup 2 --no-cpu-baseline $*"
+WARM=${PROFILE_WARMUP:-10}      # the card ramps its clocks over the first ~10 launches of a fresh process
+ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline $*"
 run() { name=$1; shift; timeout -k 10 600 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1; echo "$TAG $name rc=$?"; }
 run trace --kernel-trace --stats
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE

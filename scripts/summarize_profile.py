@@ -33,8 +33,8 @@ def short(name):
 
 
 lines = [f"# rocprofv3 summary `{tag}`", "",
-         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline " + " ".join(sys.argv[3:]) + "`",
-         "(scripts/profile.sh; the 2 warm-up launches are included in the averages).", ""]
+         "Command per pass: `rocprofv3 <pass flags> --output-format csv -- python3 bench.py --steps " + os.environ.get("PROFILE_STEPS", "20") + " --warmup " + os.environ.get("PROFILE_WARMUP", "10") + " --no-cpu-baseline " + " ".join(sys.argv[3:]) + "`",
+         "(scripts/profile.sh; rocprofv3's own averages include the warm-up launches).", ""]
 
 # ---- pass 1: kernel stats ----
 def newest(pattern):
@@ -59,6 +59,22 @@ if stats:
             lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['MinNs'])/1e6:.3f} | "
                          f"{float(r['MaxNs'])/1e6:.3f} | {r['Percentage']} |")
     lines.append("")
+    # the same pass launch by launch: rocprofv3's average spans the warm-up launches, during which the card is still ramping
+    # its clocks (the first update launch takes about twice as long); the timed region of bench.py is the LAST `steps` launches
+    tr = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if tr:
+        per = defaultdict(list)
+        for r in csv.DictReader(open(tr[0])):
+            if "vit::" in r["Kernel_Name"]:
+                per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        steps = int(os.environ.get("PROFILE_STEPS", "20"))
+        lines += [f"Launch by launch (same pass; bench.py times the last {steps} launches of each kernel, the ones before are warm-up):", "",
+                  "| kernel | launches | avg ms, timed launches only | median ms | first launch ms |", "|---|---|---|---|---|"]
+        for k, v in per.items():
+            if len(v) > steps:
+                t = sorted(v[-steps:])
+                lines.append(f"| `{k}` | {len(v)} | {sum(t)/len(t):.3f} | {t[len(t)//2]:.3f} | {v[0]:.3f} |")
+        lines.append("")
 
 # ---- PMC passes ----
 counters = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values per dispatch]
