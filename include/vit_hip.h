@@ -43,6 +43,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Batch calls only enqueue work: no
  *     allocation, no synchronisation, safe to capture into a hipGraph.
  *   - N = 2^(K-1) states, H = N/2, W = max(N/64, 1) 64-bit decision words per step, S = L + K-1 steps per frame.
+ *   - threads: the reference keeps one Core per thread and shares the const branch table (examples/run_benchmark.cpp:193-197,
+ *     viterbi_branch_table.h:17-18).  Here a handle plays the table's part for the BATCH calls: they read the handle and
+ *     write only caller-owned buffers (workspace, outputs), so several threads / streams may issue them on one handle at
+ *     once as long as each call in flight has its own workspace.  The HOST-route calls (vit_hip_update_host,
+ *     vit_hip_chainback_host) stage through buffers the handle owns, and vit_hip_set_plan / vit_hip_destroy modify it: one
+ *     thread at a time per handle for those (one handle per thread, as one Core per thread in the reference).
  */
 #ifndef VIT_HIP_H
 #define VIT_HIP_H
