@@ -5,7 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "viterbi_hip/viterbi_decoder_core.h"
@@ -73,6 +75,31 @@ int main() {
         HIP_OK(hipMemcpy(b.data(), d_out2, b.size(), hipMemcpyDeviceToHost));
         if (memcmp(a.data(), b.data(), a.size()) != 0) { printf("pipeline bytes differ from the serial decode\nFAIL\n"); return 1; }
         hipFree(d_out2);
+    }
+
+    // one decoder shared by two host threads, as the reference shares one branch table between the Cores of its worker
+    // threads (run_benchmark.cpp:193-197): each thread decodes its half of the batch with its own workspace and stream, five
+    // times over; the bytes must be those of the single call above (vit_hip.h, "threads")
+    {
+        const size_t half = frames / 2;
+        std::atomic<int> fails{0};
+        uint8_t* d_out3;
+        if (hipMalloc((void**)&d_out3, frames * out_bytes) != hipSuccess) { printf("hipMalloc failed\nFAIL\n"); return 1; }
+        auto worker = [&](size_t f0, size_t nf) {
+            void* ws = nullptr; hipStream_t st = nullptr;
+            const size_t wb = batch.workspace_bytes(nf, L);
+            if (hipMalloc(&ws, wb) != hipSuccess || hipStreamCreate(&st) != hipSuccess) { fails++; return; }
+            for (int r = 0; r < 5; r++) batch.decode(d_sym + f0 * S * R, nf, L, ws, wb, d_out3 + f0 * out_bytes, nullptr, nullptr, nullptr, st);
+            if (hipStreamSynchronize(st) != hipSuccess) fails++;
+            hipStreamDestroy(st); hipFree(ws);
+        };
+        std::thread ta(worker, size_t(0), half), tb(worker, half, frames - half);
+        ta.join(); tb.join();
+        std::vector<uint8_t> a(frames * out_bytes), b(frames * out_bytes);
+        HIP_OK(hipMemcpy(a.data(), d_out, a.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(b.data(), d_out3, b.size(), hipMemcpyDeviceToHost));
+        if (fails.load() || memcmp(a.data(), b.data(), a.size()) != 0) { printf("two threads on one decoder: bytes differ from the single call\nFAIL\n"); return 1; }
+        hipFree(d_out3);
     }
 
     std::vector<uint8_t> out(frames * out_bytes);
