@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
                     help="2: double-buffered decision workspaces, chainback of step i on a second HIP stream beside the "
-                         "update of step i+1; 1: both kernels back to back on one stream")
+                         "update of step i+1; 1: both kernels back to back on one stream; 0 (default): the rule of "
+                         "vit_hip_pipeline_submit -- 2 for the register plan with at most two update waves per SIMD (the "
+                         "headline configuration), else 1")
     ap.add_argument("--synth", default="hip", choices=["hip", "torch"],
                     help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
     return ap.parse_args()
@@ -299,6 +301,11 @@ def main():
     # bit chase, so step i's chainback runs beside step i+1's update.  Every step still does all of its work on the same
     # resident batch; only the schedule overlaps.
     NWS = args.pipeline
+    if NWS == 0:
+        # vit_hip_pipeline_create's rule: the overlap pays while the update leaves registers and issue slots free
+        dec._handle.refresh()
+        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        NWS = 2 if (dec.plan == _lib.PLAN_REG and F <= 2 * simds * dec._handle.info.workspace_tile_frames) else 1
     wss = [dec.new_workspace(F, L) for _ in range(NWS)]
     s_upd = torch.cuda.current_stream(dev)
     cb_prio = int(os.environ.get("VIT_BENCH_CB_PRIORITY", "-1"))  # high priority: the short bit chase gets out of the way of the update

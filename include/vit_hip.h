@@ -161,7 +161,10 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  * idle.  A pipeline owns two decision workspaces and two HIP streams and runs the chainback of batch i beside the update of
  * batch i+1 (the schedule bench.py measures: K = 7 soft16 4.15 -> 3.46 ms per 65536-frame batch).  submit() only enqueues
  * and returns; batches complete in order; the caller's symbol and output buffers of a batch must stay untouched until a
- * later sync() (or until `done_event`, an optional hipEvent_t passed as void*, has fired). */
+ * later sync() (or until `done_event`, an optional hipEvent_t passed as void*, has fired).
+ * The overlap is applied where it pays -- the register plan with at most two update waves per SIMD (batches of up to
+ * 2 x 4 x CUs x workspace_tile_frames frames: 65536 at K = 7, 9 on an MI355X); larger batches and the LDS plans fill the
+ * CUs by themselves, a chainback in their way costs more than it hides, and submit() runs those back to back. */
 typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,

@@ -203,22 +203,24 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
             assert np.array_equal(dec.decode(view, L).cpu().numpy(), want), (off, plan)
 
 
-def test_decode_pipeline_matches_serial_decode():
-    """vit_hip_pipeline_*: the double-buffered schedule (chainback of batch i beside the update of batch i+1) returns the
-    bytes of the serial vit_hip_decode_batch for every batch, including batches smaller than the pipeline's maximum."""
+@pytest.mark.parametrize("code_id,F,L", [(2, 2048, 1024),     # register plan, small batch: chainback beside the next update
+                                         (7, 24, 256)])       # K = 15 (PLAN_LDS2): submit() runs the two back to back
+def test_decode_pipeline_matches_serial_decode(code_id, F, L):
+    """vit_hip_pipeline_*: the double-buffered schedule (chainback of batch i beside the update of batch i+1, where that
+    pays) returns the bytes of the serial vit_hip_decode_batch for every batch, including batches smaller than the
+    pipeline's maximum."""
     import ctypes as C
     import torch
 
-    code = COMMON_CODES[2]
+    code = COMMON_CODES[code_id]
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     lib = _lib.load()
-    F, L = 2048, 1024
     pipe = C.c_void_p()
     assert lib.vit_hip_pipeline_create(dec._handle._h, F, L, C.byref(pipe)) == _lib.OK
     batches, outs = [], []
     for k in range(5):
-        n = F if k != 3 else 777
+        n = F if k != 3 else max(F // 3, 1)
         tx, sym = dec.synth(n, L, 2.0, seed=50 + k)
         out = torch.zeros((n, L // 8), dtype=torch.uint8, device="cuda")
         batches.append((n, sym, tx))

@@ -603,6 +603,7 @@ struct vit_hip_pipeline {
     hipEvent_t upd_done[2] = {nullptr, nullptr}, cb_done[2] = {nullptr, nullptr};
     bool cb_pending[2] = {false, false};
     unsigned long long n = 0;
+    size_t overlap_max_frames = 0;   // largest batch whose chainback is worth running beside the next update
 };
 
 extern "C" {
@@ -616,6 +617,15 @@ int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_h
     if (!p) return fail(VIT_HIP_ERR_RUNTIME, "out of host memory");
     p->h = h; p->max_frames = max_frames; p->L = L;
     p->ws_bytes = vit_hip_workspace_bytes(h, max_frames, L);
+    // The overlap pays while the update leaves register file and issue slots free: PLAN_REG with at most two update waves per
+    // SIMD (a 140-register wave; the chainback's 166 make a third resident).  A larger batch fills the SIMDs by itself, and
+    // the PLAN_LDS2 / PLAN_LDS update takes whole CUs: there a chainback in the way only costs (measured: K7 131072 frames
+    // 8.70 ms overlapped vs 8.10 ms back to back; K15 55.1 vs 54.8), so those batches run back to back on one stream.
+    {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        p->overlap_max_frames = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)2 * 4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
+    }
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
     bool ok = hipStreamCreateWithFlags(&p->s_upd, hipStreamNonBlocking) == hipSuccess &&
@@ -645,12 +655,16 @@ int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t 
     int rc = vit_hip_update_batch(p->h, d_symbols, frames, p->L + (size_t)p->h->K - 1, p->L, p->ws[k], p->ws_bytes, nullptr, nullptr,
                                   nullptr, p->s_upd);
     if (rc != VIT_HIP_OK) return rc;
-    VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], p->s_upd));
-    VIT_HIP_CHECK(hipStreamWaitEvent(p->s_cb, p->upd_done[k], 0));
-    rc = vit_hip_chainback_batch(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, p->s_cb);
+    hipStream_t s_cb = p->s_upd;                                // back to back unless the overlap pays (pipeline_create)
+    if (frames <= p->overlap_max_frames) {
+        s_cb = p->s_cb;
+        VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], p->s_upd));
+        VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
+    }
+    rc = vit_hip_chainback_batch(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, s_cb);
     if (rc != VIT_HIP_OK) return rc;
-    VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], p->s_cb));
-    if (done_event) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, p->s_cb));
+    VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], s_cb));
+    if (done_event) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, s_cb));
     p->cb_pending[k] = true;
     p->n++;
     return VIT_HIP_OK;
