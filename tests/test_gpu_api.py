@@ -5,8 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from viterbidecodercpp_amd import (COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib,
-                                   get_decoding_config, synth)
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, _lib, synth
 from tests.helpers import check_batch_against_oracle, make_table_config
 
 pytestmark = pytest.mark.gpu

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, _lib, synth
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, _lib
 from tests.helpers import make_table_config, oracle_cfg
 
 pytestmark = pytest.mark.gpu

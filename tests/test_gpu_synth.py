@@ -3,7 +3,7 @@ checked against the reference's encoder (oracle/_ref), the C restatement, and th
 import numpy as np
 import pytest
 
-from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, synth
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, synth
 from viterbidecodercpp_amd.tools import run_snr_ber
 from tests.helpers import make_table_config, oracle_cfg
 
