@@ -425,6 +425,14 @@ def main():
             "peak_source": f"{N_SIMD} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES_PER_INSTR} cycles per packed-16 VALU instruction "
                            "(profiles/r1_valu_issue_rates.txt)",
             "insts_source": traffic_src}
+        # the hardware's own issue rate depends on how many waves share a SIMD (profiles/r2_dep_rate.txt: an independent
+        # stream of v_pk_add_u16 issues at 5.27 / 4.52 / 4.40 / 4.29 cycles with 1 / 2 / 3 / 4 waves): the batch decides that
+        dec._handle.refresh()
+        if dec.plan == _lib.PLAN_REG:
+            waves = -(-F // dec._handle.info.workspace_tile_frames) / float(N_SIMD)
+            cyc = 5.27 if waves <= 1 else 4.52 if waves <= 2 else 4.40 if waves <= 3 else 4.29
+            result["roofline_valu"]["update_waves_per_simd"] = waves
+            result["roofline_valu"]["frac_of_issue_rate_at_that_occupancy"] = ach / (N_SIMD * CLOCK_GHZ / cyc)
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
