@@ -54,9 +54,10 @@ VIT_L2 u32 l2_sub_sat_s(u32 a, u32 b) {
     asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-VIT_L2 u32 l2_and_or(u32 a, u32 mask, u32 c) {
+// (a & mask) | (b & ~mask)
+VIT_L2 u32 l2_bfi(u32 mask, u32 a, u32 b) {
     u32 d;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
     return d;
 }
 VIT_L2 void l2_opaque(u32& x) { asm volatile("" : "+v"(x)); }   // the compiler may not assume anything about x across this point
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
         // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
         constexpr u32 SIGN_BYTES = 0x0b0a0908u;
-        u32 lo4 = 0;
+        u32 lo4 = 0, sg4[4] = {0u, 0u, 0u, 0u};
         l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value;
             constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1)), r1 = r0 | (1 << PB);
@@ -364,11 +365,16 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
             const u32 d0 = l2_sub_sat_s(y0, x0);       // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
             const u32 d1 = l2_sub_sat_s(y1, x1);
             const u32 sg = __builtin_amdgcn_perm(d1, d0, SIGN_BYTES);
-            // one chain: 1 and + 7 and_or (a second chain would cost a join)
-            if constexpr (h == 0) lo4 = sg & 0x01010101u;
-            else lo4 = l2_and_or(sg, 0x01010101u << h, lo4);
-            // four butterflies in flight at a time: the temporaries of eight do not fit beside two groups of metrics
-            if constexpr (GPT == 2 && (h & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            // a tree of bit-field inserts over the clean bytes, four butterflies at a time: 3 + 3 + 1 inserts for the eight
+            // perms (the accumulate-by-and_or chain took 8): bit h of every byte <- butterfly h
+            sg4[h & 3] = sg;
+            if constexpr ((h & 3) == 3) {
+                const u32 nib = l2_bfi(0x33333333u, l2_bfi(0x55555555u, sg4[0], sg4[1]), l2_bfi(0x55555555u, sg4[2], sg4[3]));
+                if constexpr (h == 3) lo4 = nib;
+                else lo4 = l2_bfi(0x0F0F0F0Fu, lo4, nib);
+                // four butterflies in flight at a time: the temporaries of eight do not fit beside two groups of metrics
+                if constexpr (GPT == 2) __builtin_amdgcn_sched_barrier(0);
+            }
         });
         *wdst = lo4;
     };

@@ -63,9 +63,10 @@ VIT_DEV u32 pk_max_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
 }
 // (a & mask) | c in one instruction (hipcc otherwise splits the shift-in chain of the decision gather into and + or/bitop3)
-VIT_DEV u32 and_or(u32 a, u32 mask, u32 c) {
+// (a & mask) | (b & ~mask)
+VIT_DEV u32 bfi_s(u32 mask, u32 a, u32 b) {
     u32 d;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask), "v"(c));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
     return d;
 }
 VIT_DEV u32 pk_min_s(u32 a, u32 b) {
@@ -567,19 +568,17 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         constexpr int rr = decltype(rc)::value;
                         if constexpr (rr < NREG) return D[rr]; else return 0u;
                     };
-                    // ONE chain: 8 perms + 1 and + 7 and_or (a second chain would cost a join; the chain's latency hides behind
-                    // the other wave and the next step's adds)
-                    u32 ch = 0;
+                    // a tree of bit-field inserts over the CLEAN bytes: 8 perms + 4 + 2 + 1 (one fewer than the chain, depth 4)
+                    u32 P[8];
                     static_for<4>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         constexpr int r = 16 * d + k;
-                        const u32 pl = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), SIGN_BYTES);
-                        const u32 ph = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), SIGN_BYTES);
-                        if constexpr (k == 0) ch = pl & 0x01010101u;
-                        else ch = and_or(pl, 0x01010101u << k, ch);
-                        ch = and_or(ph, 0x10101010u << k, ch);
+                        P[k] = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), SIGN_BYTES);
+                        P[k + 4] = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), SIGN_BYTES);
                     });
-                    acc[d] = ch;
+                    const u32 q0 = bfi_s(0x55555555u, P[0], P[1]), q1 = bfi_s(0x55555555u, P[2], P[3]);
+                    const u32 q2 = bfi_s(0x55555555u, P[4], P[5]), q3 = bfi_s(0x55555555u, P[6], P[7]);
+                    acc[d] = bfi_s(0x0F0F0F0Fu, bfi_s(0x33333333u, q0, q1), bfi_s(0x33333333u, q2, q3));
                 };
                 // 64-register codes (K = 9): a 16-register chunk is gathered as soon as its butterflies are done and the
                 // scheduler may not move work across that point -- 64 metrics + 64 live decision values + branch metrics + index
