@@ -88,7 +88,7 @@ typedef struct vit_hip_info {
     uint32_t polynomials[16];                      /* recovered G[i] (bit 0 and bit K-1 forced to 1), 0 if not linear */
     int32_t table_is_linear;
     int32_t workspace_tile_frames; /* the decision workspace is an array of independent slabs of this many frames: frame f
-                                      lives in slab f / tile, which starts vit_hip_workspace_bytes(h, tile, L) * (f / tile)
+                                      lives in slab f / tile, which starts vit_hip_workspace_slab_bytes(h, L) * (f / tile)
                                       bytes into the workspace -- a slab-aligned sub-range of a batch can be chained back or
                                       exported on its own by passing that address */
 } vit_hip_info;
@@ -118,6 +118,10 @@ int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vi
 
 /* bytes of decision workspace needed for `frames` frames of L info bits (layout is plan-specific and opaque). */
 size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L);
+/* bytes between consecutive slabs of vit_hip_info.workspace_tile_frames frames inside a workspace.  Not the same as
+ * vit_hip_workspace_bytes(h, tile, L): that is rounded up to 256 bytes, the slab stride of PLAN_LDS (the dense reference
+ * layout [F][S][W]) is not.  vit_hip_chainback_batch and vit_hip_export_decisions accept any slab address. */
+size_t vit_hip_workspace_slab_bytes(vit_hip_handle h, size_t L);
 
 /* reset(start_state) + update() over n_steps trellis steps (n_steps <= L + K-1) for every frame.
  *   d_symbols       [frames][n_steps][R] soft_t, frame-major, step-major, polynomial-minor

@@ -34,6 +34,15 @@ public:
     soft_t* data() { return m_rows[0].data(); }               // writable: the receiving side of vit_hip_broadcast_table
     soft_t soft_decision_high() const { return m_high; }
     soft_t soft_decision_low() const { return m_low; }
+    // after the rows were overwritten through data() (the receiving side of vit_hip_broadcast_table): recover high / low from
+    // them -- row entry 0 is always `low` (parity of half-state 0 is 0), any other value in the table is `high`
+    void refresh_levels() {
+        m_low = m_rows[0][0];
+        m_high = m_low;
+        for (size_t i = 0; i < R; i++)
+            for (size_t s = 0; s < NUMSTATES; s++)
+                if (m_rows[i][s] != m_low) { m_high = m_rows[i][s]; return; }
+    }
 
 private:
     soft_t m_high, m_low;

@@ -89,6 +89,7 @@ public:
                                 void* stream = nullptr) {
         check(vit_hip_broadcast_table(nccl_comm, root, rank, int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)),
                                       table.data(), &config, device, stream), "vit_hip_broadcast_table");
+        if (rank != root) table.refresh_levels();   // soft_decision_high()/low() must describe the rows that were received
     }
     vit_hip_handle hip_handle() const { return m_hip; }
 

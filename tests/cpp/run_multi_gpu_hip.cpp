@@ -45,7 +45,8 @@ static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_
     Batch::broadcast_table(comm, 0, rank, table, config, rank, st);
     const auto want = ViterbiBranchTable<K, R, int16_t>(G, setup.high, setup.low);
     res->table_ok = memcmp(table.data(), want.data(), R * 32 * sizeof(int16_t)) == 0 &&
-                    memcmp(&config, &setup.config, sizeof(config)) == 0;
+                    memcmp(&config, &setup.config, sizeof(config)) == 0 &&
+                    table.soft_decision_high() == setup.high && table.soft_decision_low() == setup.low;
 
     Batch dec(table, config, rank);
     const size_t S = L + K - 1, out_bytes = L / 8, ws_bytes = dec.workspace_bytes(frames, L);

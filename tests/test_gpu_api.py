@@ -232,3 +232,46 @@ def test_decode_pipeline_matches_serial_decode(code_id, F, L):
     for (n, sym, tx), out in zip(batches, outs):
         assert torch.equal(out, dec.decode(sym, L))
     assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK
+
+
+@pytest.mark.parametrize("K,R,G,plan,F,L", [
+    (10, 2, (0o1167, 0o1545), _lib.PLAN_LDS, 7, 100),     # dense [F][S][W]: slab stride 109 * 8 * 8 = 6976 B, not a multiple of 256
+    (6, 2, (0o65, 0o57), _lib.PLAN_LDS, 9, 33),           # W = 1: 304-byte slabs
+    (7, 2, (109, 79), _lib.PLAN_REG, 70, 100),            # 32-frame tiles
+    (11, 2, (0o3345, 0o3613), _lib.PLAN_LDS2, 7, 40),     # frame pairs
+])
+def test_slab_sub_range_export_and_chainback(oracle, K, R, G, plan, F, L):
+    """vit_hip_info.workspace_tile_frames / vit_hip_workspace_slab_bytes: the rows of a slab-aligned sub-range of a batch
+    are exported and chained back from the slab's address alone -- on every plan, including PLAN_LDS whose slab stride is the
+    dense S*W*8 bytes of the reference layout and not the 256-byte-rounded vit_hip_workspace_bytes(h, 1, L)."""
+    import ctypes as C
+    import torch
+    from oracle import pyoracle
+
+    code = Code(f"K{K}", K, R, G)
+    pc, table, config = make_table_config(code, "SOFT16")
+    ocfg = pyoracle.stock_config(pyoracle.SOFT16, R)
+    _, sym = synth.make_frames_numpy(code, pc, F, L, 1.0, seed=K)
+    dec = BatchDecoder(table, config, plan=plan)
+    assert dec.plan == plan
+    dec.update(torch.from_numpy(sym).cuda(), L)
+    lib = _lib.load()
+    dec._handle.refresh()
+    tile = dec._handle.info.workspace_tile_frames
+    slab = lib.vit_hip_workspace_slab_bytes(dec._handle._h, L)
+    assert tile >= 1 and slab > 0
+    if plan == _lib.PLAN_LDS:
+        assert slab == (L + K - 1) * dec.W * 8 and (K != 10 or slab % 256 != 0)
+    whole = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
+    for f0 in range(0, F, tile):
+        n = min(tile, F - f0)
+        part = dec.export_decisions(n, L, first_frame=f0).cpu().numpy().view(np.uint64)
+        assert np.array_equal(part, whole[f0:f0 + n]), f0
+        out = torch.zeros((n, L // 8 + (1 if L % 8 else 0)), dtype=torch.uint8, device="cuda")
+        rc = lib.vit_hip_chainback_batch(dec._handle._h, C.c_void_p(dec._ws.data_ptr() + (f0 // tile) * slab), n, L,
+                                         C.c_void_p(out.data_ptr()), None, None)
+        assert rc == _lib.OK
+        for f in range(f0, f0 + n, max(1, n // 3)):
+            want = oracle.decode(K, R, G, ocfg, sym[f], L)
+            assert np.array_equal(part[f - f0], want["decisions"]), f
+            assert np.array_equal(out[f - f0].cpu().numpy(), want["bytes"]), f

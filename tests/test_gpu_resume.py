@@ -4,7 +4,7 @@ must give the same decision rows, metrics, renormalisation sums and bytes as one
 import numpy as np
 import pytest
 
-from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, _lib, synth
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, ViterbiBranchTable, ViterbiDecoder_Config, _lib, synth
 from tests.helpers import gpu_metrics_to_u32, make_table_config, oracle_frames
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +58,7 @@ def test_chunked_update_equals_one_call_and_the_oracle(oracle, case, style):
     rng = np.random.default_rng(1000 * case + len(style))
     ebn0 = 1.0 if code.K < 15 else -4.0
     _, sym = synth.make_frames_numpy(code, pc, F, L, ebn0, seed=case)
-    # small thresholds make renormalisation frequent so that chunk boundaries meet it in every position
+    # stock configuration here; test_chunked_update_with_frequent_renormalisation below lowers the threshold
     start = rng.integers(0, code.num_states, F).astype(np.int32)
     end = rng.integers(0, code.num_states, F).astype(np.int32)
     d_sym = torch.from_numpy(sym).cuda()
@@ -95,6 +95,64 @@ def test_chunked_update_equals_one_call_and_the_oracle(oracle, case, style):
     assert np.array_equal(out1.cpu().numpy(), want["bytes"])
 
 
+LOW_THR_CASES = [
+    (COMMON_CODES[2], 2, _lib.PLAN_REG, 45, 150),      # K7 soft16
+    (COMMON_CODES[2], 1, _lib.PLAN_REG, 33, 150),      # K7 u8
+    (COMMON_CODES[5], 2, _lib.PLAN_REG, 34, 90),       # K9
+    (COMMON_CODES[1], 2, _lib.PLAN_REG, 130, 90),      # K5: all states in one lane
+    (K11, 2, _lib.PLAN_LDS2, 4, 60),
+    (COMMON_CODES[7], 2, _lib.PLAN_LDS2, 3, 33),       # K15: careful blocks predicted at every block position
+    (K6, 2, _lib.PLAN_LDS, 4, 80),
+]
+
+
+@pytest.mark.parametrize("case", range(len(LOW_THR_CASES)))
+def test_chunked_update_with_frequent_renormalisation(oracle, case):
+    """A threshold a few steps' worth of error above the initial metrics: state 0 crosses it every two to six steps, so
+    renormalisation lands on chunk boundaries, inside resumed entry blocks and (PLAN_LDS2) at every position of a radix-16
+    block.  Chunks of every length 1..9 in turn; results must equal one call and the oracle."""
+    import torch
+    from oracle import pyoracle
+
+    code, width, plan, F, L = LOW_THR_CASES[case]
+    S = L + code.K - 1
+    rng = np.random.default_rng(4200 + case)
+    if width == 2:
+        cfg = pyoracle.DecodeConfig(2, 2, 127, -127, 254 * code.R, 0, 300, 700)
+    else:
+        cfg = pyoracle.DecodeConfig(1, 1, 3, -3, 6 * code.R, 0, 10, 25)
+    sdt = np.int16 if width == 2 else np.int8
+    table = ViterbiBranchTable(code.K, code.R, code.G, cfg.high, cfg.low, sdt)
+    config = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error,
+                                   cfg.renormalisation_threshold, np.uint16 if width == 2 else np.uint8)
+    sym = rng.integers(cfg.low, cfg.high + 1, size=(F, S, code.R)).astype(sdt)
+    start = rng.integers(0, code.num_states, F).astype(np.int32)
+    end = rng.integers(0, code.num_states, F).astype(np.int32)
+    want = [oracle.decode(code.K, code.R, code.G, cfg, sym[f], L, start_state=int(start[f]), end_state=int(end[f]))
+            for f in range(F)]
+    assert min(w["renorm_sum"] for w in want) > 0, "the configuration must renormalise in every frame"
+    d_sym = torch.from_numpy(sym).cuda()
+    dec = BatchDecoder(table, config, plan=plan)
+    ws = dec.new_workspace(F, L)
+    ws.fill_(0x5A)
+    met = dec.reset_batch(F, start_state=start)
+    rs = torch.zeros(F, dtype=torch.int64, device="cuda")
+    t, k = 0, 0
+    while t < S:
+        n = min(1 + k % 9, S - t)
+        rs += dec.update_resume(d_sym.reshape(-1)[t * code.R:], L, t, met, n_steps=n, symbol_frame_stride=S * code.R, workspace=ws)
+        t += n
+        k += 1
+    got_dec = dec.export_decisions(F, L, workspace=ws).cpu().numpy().view(np.uint64)
+    out = dec.chainback(F, L, end_state=end, workspace=ws).cpu().numpy()
+    m = gpu_metrics_to_u32(met, width)
+    for f in range(F):
+        assert np.array_equal(got_dec[f], want[f]["decisions"]), f
+        assert np.array_equal(m[f], want[f]["metrics"]), f
+        assert int(rs[f].item()) == want[f]["renorm_sum"], f
+        assert np.array_equal(out[f], want[f]["bytes"]), f
+
+
 def test_resume_argument_checks():
     import ctypes as C
     import torch
@@ -110,6 +168,10 @@ def test_resume_argument_checks():
         dec.update_resume(sym, L, S - 5, met)
     with pytest.raises(_lib.VitHipError):           # stride shorter than a chunk
         dec.update_resume(sym, L, 0, met, symbol_frame_stride=3)
+    with pytest.raises(ValueError):                 # a view too short for the last frame's chunk
+        dec.update_resume(sym.reshape(-1)[:F * 10 * code.R - 8], L, 0, met, n_steps=10, symbol_frame_stride=10 * code.R)
+    with pytest.raises(ValueError):                 # packed chunks of the wrong rate
+        dec.update_resume(torch.zeros((F, 10, code.R + 1), dtype=torch.int16, device="cuda"), L, 0, met)
     lib = _lib.load()
     ws = dec.new_workspace(F, L)
     rc = lib.vit_hip_update_batch_resume(dec._handle._h, C.c_void_p(sym.data_ptr()), 0, F, 0, 10, L, C.c_void_p(ws.data_ptr()),

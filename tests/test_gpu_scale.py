@@ -78,6 +78,44 @@ def _every_frame_exact(oracle, dec, code, decode_type, pc, sym, out, met, rs, fr
     assert np.array_equal(rs.cpu().numpy().astype(np.uint64), want_rs)
 
 
+def _slabs_exact_by_digest(oracle, dec, code, decode_type, pc, sym, out, met, rs, frames, L, n_slabs, budget_note):
+    """`n_slabs` whole workspace slabs spread evenly over the batch, every frame of each against the C restatement run on all
+    host cores: bytes, metrics, renormalisation sums and the 64-bit digest over every decision word (the K = 15 form of
+    _every_frame_exact: the scalar oracle needs ~0.75 s per 8192-bit Cassini frame)."""
+    import torch
+
+    S, W = L + code.K - 1, dec.W
+    dec._handle.refresh()
+    tile = dec._handle.info.workspace_tile_frames
+    n_tiles = (frames + tile - 1) // tile
+    slabs = sorted(set(int(x) for x in np.linspace(0, n_tiles - 1, n_slabs).round()))
+    ids = np.asarray([f for sl in slabs for f in range(sl * tile, min((sl + 1) * tile, frames))])
+    threads = len(os.sched_getaffinity(0))
+    d_ids = torch.from_numpy(ids).to(sym.device)
+    want_out, want_met, want_rs, want_hash = oracle.decode_frames(
+        code.K, code.R, code.G, oracle_cfg(decode_type, code.R), sym[d_ids].cpu().numpy(), L, threads=threads,
+        want_metrics=True, want_hash=True)
+    with np.errstate(over="ignore"):
+        mul = (2 * np.arange(S * W, dtype=np.uint64) + 1) * np.uint64(oracle.HASH_MUL)
+    mul = torch.from_numpy(mul.view(np.int64)).to(sym.device)
+    got_hash = []
+    for sl in slabs:
+        f0 = sl * tile
+        n = min(tile, frames - f0)
+        words = dec.export_decisions(n, L, first_frame=f0).view(n, S * W)
+        got_hash.append((words * mul).sum(dim=1))
+        del words
+    got_hash = torch.cat(got_hash).cpu().numpy().view(np.uint64)
+    bad = np.nonzero(got_hash != want_hash)[0]
+    assert bad.size == 0, f"{budget_note}: decision words differ in frames {ids[bad][:8]}"
+    assert np.array_equal(out[d_ids].cpu().numpy(), want_out), budget_note
+    m = met[d_ids].cpu().numpy()
+    m = m.view(np.uint16) if pc.error_bytes == 2 else m
+    assert np.array_equal(m, want_met.astype(m.dtype)), budget_note
+    assert np.array_equal(rs[d_ids].cpu().numpy().astype(np.uint64), want_rs), budget_note
+    return len(ids)
+
+
 @pytest.mark.parametrize("code_id,decode_type,frames,L,ebn0,ber_max", [
     (2, "SOFT16", 65536, 8192, 3.0, 2e-3),    # BASELINE configs[1]: K=7 R=1/2 u16, 64k frames x 8192 bits
     (5, "SOFT16", 65536, 8192, 3.0, 1e-3),    # configs[2]: K=9 R=1/2 u16, 64k frames (17.2 GB of decision rows)
@@ -134,3 +172,8 @@ def test_cassini_k15_full_size(oracle):
     ber = int(dec.count_bit_errors(out, tx).item()) / float(frames * L)
     assert 1e-4 < ber < 0.1, ber              # ~1e-2 at 1 dB
     _oracle_subset(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L, n_pick=4, seed=3)
+    # ... and 32 whole frames per host thread through the threaded oracle (about 25 s of wall clock on the box's 16 cores:
+    # 512 of the 4096 frames), compared by digest over all 2.1 M decision words of each
+    n = _slabs_exact_by_digest(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L,
+                               n_slabs=16 * len(os.sched_getaffinity(0)), budget_note="K15 full size, noisy batch")
+    assert n >= 32

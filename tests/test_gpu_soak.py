@@ -1,4 +1,4 @@
-"""A 45-second slice of the randomised soak (tests/soak_fuzz.py) under pytest, so that the driver's GPU run carries it: random
+"""Two slices (one fixed-seed, one date-seeded, 45 s) of the randomised soak (tests/soak_fuzz.py) under pytest, so that the driver's GPU run carries it: random
 decoder configurations, batch shapes, start/end states and in-range or full-range symbols over eleven codes and all three
 kernel plans, one case in three streamed through the resumed update -- every result bit-exact against the oracle."""
 import time
@@ -6,6 +6,15 @@ import time
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(300)
+def test_soak_slice_fixed_seed():
+    """the same cases on every run of a commit: a red run is reproducible from the log alone"""
+    from tests.soak_fuzz import soak
+
+    n = soak(25.0, 424242)
+    assert n >= 100, n
 
 
 @pytest.mark.timeout(300)

@@ -21,7 +21,7 @@ PLAN_NAMES = {PLAN_LDS: "lds", PLAN_REG: "reg", PLAN_LDS2: "lds2"}
 EXPORTS = [
     "vit_hip_last_error", "vit_hip_device_count", "vit_hip_create", "vit_hip_destroy", "vit_hip_get_info",
     "vit_hip_set_plan", "vit_hip_blob_bytes", "vit_hip_pack_blob", "vit_hip_create_from_blob",
-    "vit_hip_workspace_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
+    "vit_hip_workspace_bytes", "vit_hip_workspace_slab_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
     "vit_hip_export_decisions", "vit_hip_depuncture_batch", "vit_hip_update_host", "vit_hip_chainback_host",
     "vit_hip_reset_batch", "vit_hip_update_batch_resume", "vit_hip_broadcast_table", "vit_hip_synth_batch",
     "vit_hip_count_bit_errors", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
@@ -71,6 +71,8 @@ def load():
     L.vit_hip_create_from_blob.argtypes = [vp, sz, i32, C.POINTER(vp)]
     L.vit_hip_workspace_bytes.restype = sz
     L.vit_hip_workspace_bytes.argtypes = [vp, sz, sz]
+    L.vit_hip_workspace_slab_bytes.restype = sz
+    L.vit_hip_workspace_slab_bytes.argtypes = [vp, sz]
     L.vit_hip_update_batch.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, vp, vp, vp]
     L.vit_hip_chainback_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.vit_hip_decode_batch.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, vp, vp, vp]

@@ -60,6 +60,14 @@ VIT_L2 u32 l2_bfi(u32 mask, u32 a, u32 b) {
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
     return d;
 }
+// "this wavefront's LDS reads of the block's inputs (and its table writes) are done": a RELEASE on the LDS address space in
+// front of the counter's add, so that neither the compiler nor the memory model may sink those accesses below it (a relaxed
+// add left that to the scheduler's good will).  The fence is restricted to LDS: a generic release would also wait for the
+// decision stores to HBM that are still in flight from the previous block (s_waitcnt vmcnt(0)).
+VIT_L2 void lds2_arrive(u32* counter, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 VIT_L2 void l2_opaque(u32& x) { asm volatile("" : "+v"(x)); }   // the compiler may not assume anything about x across this point
 template <class F, int... Is>
 VIT_L2 void l2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -477,7 +485,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
                 if constexpr (GPT == 2) mB[r] = met[lds2_sw(lds2_state_of(c_first - 1, r, tid_o + (u32)T, SBITS), (u32)N)];
             });
         }
-        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // keeps the fast path's count in step
+        lds2_arrive(arrive, lane);             // keeps the fast path's count in step
         __syncthreads();                       // B1: all inputs are in registers, the buffer may be overwritten
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
@@ -514,13 +522,13 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         tables_build(t0 + BLK, set ^ 1);
         // B1, split: "my loads have returned" is announced here (one LDS add per wavefront) ...
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
-        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds2_arrive(arrive, lane);
         u32* const wsp = ws_pair + (size_t)t0 * G;   // uniform: the four decision rows of this block
 
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) { stage_all(cc, wsp); });
         // ... and awaited only here, four trellis steps later, before the first store: by now every wavefront has long arrived
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrive_target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         tables_load(t0 + 2 * BLK);             // the symbols of the block after next: in flight across the barrier
         store_metrics();
         if (tid == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);

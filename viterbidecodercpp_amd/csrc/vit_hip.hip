@@ -458,6 +458,15 @@ size_t vit_hip_workspace_bytes(vit_hip_handle h, size_t frames, size_t L) {
     return align_up(frames * (L + (size_t)h->K - 1) * (size_t)h->W * 8, 256);
 }
 
+size_t vit_hip_workspace_slab_bytes(vit_hip_handle h, size_t L) {
+    if (!h) return 0;
+    // PLAN_REG: one tile of frames; PLAN_LDS2: one frame pair (rows x T dwords, T >= 64: a multiple of 256 bytes); PLAN_LDS:
+    // the reference layout [F][S][W], dense -- one frame's rows, NOT rounded up to the 256 bytes the whole workspace is
+    if (h->plan == VIT_HIP_PLAN_REG) return vit::reg_workspace_bytes(h->reg_code, (size_t)h->reg_code.tile, L);
+    if (h->plan == VIT_HIP_PLAN_LDS2) return vit::lds2_workspace_bytes(h->K, 2, L);
+    return (L + (size_t)h->K - 1) * (size_t)h->W * 8;
+}
+
 namespace {
 // reset + update (d_metrics_in == null, first_step == 0) or resumed update: one body behind both entry points
 int update_batch_impl(vit_hip_handle h, const void* d_symbols, size_t sym_stride, size_t frames, size_t first_step, size_t n_steps,
@@ -706,10 +715,10 @@ struct RcclApi {
 // The communicator belongs to the RCCL the host program uses: take the symbol from the process first (a C/C++ host that
 // links -lrccl), and load librccl.so only when the process does not export it.
 const RcclApi* rccl_api() {
-    static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    // resolved exactly once, by whichever thread gets here first (function-local static: the others wait for the
+    // initialiser to finish and then see the filled table -- one host thread per GPU calls this at the same moment)
+    static const RcclApi api = [] {
+        RcclApi a;
         void* sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
         void* lib = nullptr;
         if (!sym) {
@@ -720,53 +729,57 @@ const RcclApi* rccl_api() {
             }
             if (lib) sym = dlsym(lib, "ncclBroadcast");
         }
-        api.broadcast = (nccl_broadcast_fn)sym;
-        api.errstr = (nccl_errstr_fn)(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
-    }
+        a.broadcast = (nccl_broadcast_fn)sym;
+        a.errstr = (nccl_errstr_fn)(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+        return a;
+    }();
     return api.broadcast ? &api : nullptr;
 }
 }  // namespace
 
 static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
                             void* branch_table, void* config, int device, vit_hip_stream_t stream) {
+    // Everything that can fail locally runs BEFORE the collective and depends only on arguments every rank passes alike (K, R,
+    // widths, pointers being non-NULL), so a bad call fails on all ranks the same way and nobody is left waiting in
+    // ncclBroadcast.  Once past that point every rank enters the collective exactly once: a root that cannot fill the buffer
+    // broadcasts a poisoned header, which the other ranks report as an error.
     if (!nccl_comm || !branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     if (K < 2 || K > 16 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
         return fail(VIT_HIP_ERR_UNSUPPORTED, "unsupported (K, R, soft_t, error_t)");
     const size_t need = vit_hip_blob_bytes(K, R, soft_bytes, error_bytes);
     const RcclApi* api = rccl_api();
     if (!api) return fail(VIT_HIP_ERR_RUNTIME, "RCCL not available: ncclBroadcast is neither in the process nor in librccl.so");
-    std::vector<uint8_t> blob(need);
-    if (rank == root) {
-        const int rc = vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need);
-        if (rc != VIT_HIP_OK) return rc;
-    }
+    std::vector<uint8_t> blob(need, 0);
     DeviceGuard guard(device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     void* d_buf = nullptr;
     VIT_HIP_CHECK(hipMalloc(&d_buf, need));
+    std::string root_error;
+    if (rank == root) {
+        if (vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need) != VIT_HIP_OK) {
+            root_error = g_last_error;
+            memset(blob.data(), 0, sizeof(BlobHeader));          // poisoned: magic 0
+        }
+        if (hipMemcpyAsync(d_buf, blob.data(), need, hipMemcpyHostToDevice, st) != hipSuccess) {
+            root_error = "hipMemcpyAsync (blob to device) failed";
+            (void)hipMemsetAsync(d_buf, 0, sizeof(BlobHeader), st);
+        }
+    }
     int result = VIT_HIP_OK;
-    do {
-        if (rank == root && hipMemcpyAsync(d_buf, blob.data(), need, hipMemcpyHostToDevice, st) != hipSuccess) {
-            result = fail(VIT_HIP_ERR_RUNTIME, "hipMemcpyAsync (blob to device) failed");
-            break;
-        }
-        const int nrc = api->broadcast(d_buf, d_buf, need, 1 /* ncclUint8 */, root, nccl_comm, st);
-        if (nrc != 0) {
-            result = fail(VIT_HIP_ERR_RUNTIME, std::string("ncclBroadcast: ") + (api->errstr ? api->errstr(nrc) : "error"));
-            break;
-        }
-        if (hipMemcpyAsync(blob.data(), d_buf, need, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {
-            result = fail(VIT_HIP_ERR_RUNTIME, "copying the broadcast blob back failed");
-            break;
-        }
-    } while (false);
+    const int nrc = api->broadcast(d_buf, d_buf, need, 1 /* ncclUint8 */, root, nccl_comm, st);
+    if (nrc != 0)
+        result = fail(VIT_HIP_ERR_RUNTIME, std::string("ncclBroadcast: ") + (api->errstr ? api->errstr(nrc) : "error"));
+    else if (hipMemcpyAsync(blob.data(), d_buf, need, hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipStreamSynchronize(st) != hipSuccess)
+        result = fail(VIT_HIP_ERR_RUNTIME, "copying the broadcast blob back failed");
     (void)hipFree(d_buf);
     if (result != VIT_HIP_OK) return result;
+    if (!root_error.empty()) return fail(VIT_HIP_ERR_RUNTIME, "root rank could not pack the table: " + root_error);
     BlobHeader hd;
     memcpy(&hd, blob.data(), sizeof(hd));
-    if (hd.magic != BLOB_MAGIC || hd.K != K || hd.R != R || hd.soft_bytes != soft_bytes || hd.error_bytes != error_bytes)
+    if (hd.magic != BLOB_MAGIC) return fail(VIT_HIP_ERR_RUNTIME, "the root rank failed to pack its table (poisoned header received)");
+    if (hd.K != K || hd.R != R || hd.soft_bytes != soft_bytes || hd.error_bytes != error_bytes)
         return fail(VIT_HIP_ERR_INVALID_ARG, "the root rank broadcast a table for a different (K, R, soft_t, error_t)");
     if (rank != root) {
         const size_t tb = need - sizeof(hd) - 4 * (size_t)error_bytes;

@@ -307,6 +307,15 @@ class BatchDecoder:
             raise ValueError(f"symbols must be a {want} CUDA tensor")
         if symbol_frame_stride == 0 and not symbols.is_contiguous():
             raise ValueError("packed chunks must be contiguous (or pass symbol_frame_stride)")
+        if metrics.dim() != 2 or metrics.shape[1] != self.N or not metrics.is_contiguous():
+            raise ValueError("metrics must be a contiguous [frames][N] tensor")
+        if symbol_frame_stride == 0 and symbols.dim() == 3 and (symbols.shape[0] != frames or symbols.shape[2] != self.R):
+            raise ValueError("packed chunks must have shape [frames][n_steps][R]")
+        # the kernels read frame f's chunk at f * stride: the tensor must cover the last frame's chunk
+        stride = symbol_frame_stride or n_steps * self.R
+        if frames and symbols.numel() < (frames - 1) * stride + n_steps * self.R:
+            raise ValueError(f"symbols holds {symbols.numel()} elements; {frames} chunks of {n_steps} x {self.R} at stride "
+                             f"{stride} need {(frames - 1) * stride + n_steps * self.R}")
         ws = self._workspace(frames, L, workspace)
         rs = t.empty(frames, dtype=t.int64, device=self.device) if renorm_out is None else renorm_out
         _lib.check(_lib.load().vit_hip_update_batch_resume(
@@ -409,8 +418,12 @@ class BatchDecoder:
             if first_frame % tile:
                 raise ValueError(f"first_frame must be a multiple of {tile} for this plan")
             base = self._ws if workspace is None else workspace
-            workspace = base[(first_frame // tile) * self.workspace_bytes(tile, L):]
-        ws = self._workspace(frames, L, workspace)
+            workspace = base[(first_frame // tile) * _lib.load().vit_hip_workspace_slab_bytes(self._handle._h, L):]
+            if workspace.numel() * workspace.element_size() < self.workspace_bytes(frames, L) - 255:
+                raise ValueError("workspace too small for that sub-range")
+            ws = workspace                   # a slab address: 256-byte alignment is only asked of whole workspaces
+        else:
+            ws = self._workspace(frames, L, workspace)
         dec = t.empty((frames, n_steps, self.W), dtype=t.int64, device=self.device)
         _lib.check(_lib.load().vit_hip_export_decisions(self._handle._h, C.c_void_p(ws.data_ptr()), frames, n_steps, L,
                                                         C.c_void_p(dec.data_ptr()), self._stream()))
