@@ -34,6 +34,16 @@ CLOCK_GHZ = 2.4
 VALU_CYCLES_PER_INSTR = 4.3
 
 
+# BASELINE.json configs[i] -> (index into COMMON_CODES, decode type, frames per GPU, info bits per frame, Eb/N0 dB)
+BASELINE_CONFIGS = {
+    0: (2, "SOFT16", 1, 4096, 3.0),
+    1: (2, "SOFT16", 65536, 8192, 3.0),
+    2: (5, "SOFT16", 65536, 8192, 3.0),
+    3: (2, "HARD8", 32768, 8192, 5.0),     # 262144 frames sharded over 8 GPUs: weak scaling, one GPU's share per rank
+    4: (7, "SOFT16", 4096, 8192, 3.0),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,9 +65,22 @@ def parse():
                          "update of step i+1; 1: both kernels back to back on one stream; 0 (default): the rule of "
                          "vit_hip_pipeline_submit -- 2 for the register plan with at most two update waves per SIMD (the "
                          "headline configuration), else 1")
+    ap.add_argument("--via", default="pipeline", choices=["pipeline", "python"],
+                    help="pipeline (default): the timed loop calls the shipped C API only -- vit_hip_pipeline_submit per step, "
+                         "vit_hip_pipeline_sync at the end; the library picks the schedule (--pipeline is ignored).  python: the "
+                         "same schedule rebuilt from torch streams around vit_hip_update_batch / vit_hip_chainback_batch (A/B)")
+    ap.add_argument("--config", type=int, default=None, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[i]: 0 = K7 soft16 1 frame x 4096; 1 = K7 soft16 65536 x 8192 (the default "
+                         "workload); 2 = K9 soft16 65536 x 8192; 3 = K7 hard8, 262144 frames over 8 GPUs = 32768 per GPU "
+                         "(--gpus 8 --config 3 is the whole run); 4 = K15 soft16 4096 x 8192.  Sets --code/--decode-type/"
+                         "--frames/--bits/--ebn0")
     ap.add_argument("--synth", default="hip", choices=["hip", "torch"],
                     help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config is not None:
+        code, dt, frames, bits, ebn0 = BASELINE_CONFIGS[args.config]
+        args.code, args.decode_type, args.frames, args.bits, args.ebn0 = code, dt, frames, bits, ebn0
+    return args
 
 
 def launch_ranks(args):
@@ -199,7 +222,7 @@ def cpu_baseline(code_id, code, pc, decode_type, sym_dev, L, target_seconds):
     return res
 
 
-def reference_parity(code_id, code, pc, decode_type, dec, sym_dev, out_dev, ws, F, L, n=64):
+def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, out_dev, F, L, n=64):
     """n frames of the timed batch against the reference SCALAR decoder (oracle/_ref; the C restatement where that is
     absent): chainback bytes AND every decision word."""
     import numpy as np
@@ -211,7 +234,7 @@ def reference_parity(code_id, code, pc, decode_type, dec, sym_dev, out_dev, ws, 
     n = max(1, min(F, n if code.K < 11 else 2))
     S = L + code.K - 1
     # the workspace layout is tile-major: export the first frames only
-    got_dec = dec.export_decisions(n, L, workspace=ws).cpu().numpy().view(np.uint64)
+    got_dec = last_decisions(n).cpu().numpy().view(np.uint64)
     got_bytes = out_dev[:n].cpu().numpy()
     sym = sym_dev[:n].cpu().numpy()
     ref = pyoracle.RefLib() if pyoracle.RefLib.available() else None
@@ -297,54 +320,117 @@ def main():
     out = torch.empty((F, L // 8), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    # Two decision workspaces and two HIP streams: update() is VALU-issue bound, chainback() is a latency/HBM-bound
-    # bit chase, so step i's chainback runs beside step i+1's update.  Every step still does all of its work on the same
-    # resident batch; only the schedule overlaps.
-    NWS = args.pipeline
-    if NWS == 0:
-        # vit_hip_pipeline_create's rule: the overlap pays while the update leaves registers and issue slots free
-        dec._handle.refresh()
-        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-        NWS = 2 if (dec.plan == _lib.PLAN_REG and F <= 2 * simds * dec._handle.info.workspace_tile_frames) else 1
-    wss = [dec.new_workspace(F, L) for _ in range(NWS)]
-    s_upd = torch.cuda.current_stream(dev)
-    cb_prio = int(os.environ.get("VIT_BENCH_CB_PRIORITY", "-1"))  # high priority: the short bit chase gets out of the way of the update
-    s_cb = torch.cuda.Stream(device=dev, priority=cb_prio) if NWS == 2 else s_upd
-    cb_done = [None] * NWS
+    lib = _lib.load()
+    import ctypes as C
 
-    def one_step(k, ev=None):
-        ws = wss[k % NWS]
-        if cb_done[k % NWS] is not None:
-            s_upd.wait_event(cb_done[k % NWS])          # the chainback that last read this workspace has finished
-        if ev is not None:
-            ev[0].record(s_upd)
-        dec.update(sym, L, want_metrics=False, workspace=ws)
-        upd_done = torch.cuda.Event(enable_timing=ev is not None) if ev is None else ev[1]
-        upd_done.record(s_upd)
-        s_cb.wait_event(upd_done)
-        with torch.cuda.stream(s_cb):
-            if ev is not None and NWS == 2:
-                ev[3].record(s_cb)
-            dec.chainback(F, L, out=out, workspace=ws)
-            done = torch.cuda.Event(enable_timing=ev is not None) if ev is None else ev[2]
-            done.record(s_cb)
-        cb_done[k % NWS] = done
+    def shader_clock():
+        mhz, cyc = C.c_double(0), C.c_double(0)
+        _lib.check(lib.vit_hip_shader_clock_mhz(local_rank, C.byref(mhz), C.byref(cyc)))
+        return float(mhz.value), float(cyc.value)
 
-    for k in range(args.warmup):
-        one_step(k)
-    torch.cuda.synchronize()
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    dec._handle.refresh()
+    tile_frames = dec._handle.info.workspace_tile_frames
+    if args.via == "pipeline":
+        # ---- the shipped API: one vit_hip_pipeline_submit per step, one vit_hip_pipeline_sync at the end.  The library owns
+        # the workspaces, the streams and the schedule (include/vit_hip.h); the per-kernel durations come from its own HIP
+        # events on the streams the kernels run on (vit_hip_pipeline_set_timing).
+        from viterbidecodercpp_amd import DecodePipeline
+        pipe = DecodePipeline(dec, F, L)
+        sch = pipe.schedule
+        NWS, NUPD = int(sch.workspaces), int(sch.update_streams)
+        sched_desc = (f"vit_hip_pipeline: {NWS} workspaces, {NUPD} update stream(s), chainback "
+                      f"{'on its own stream beside the next update' if sch.chainback_overlapped else 'back to back on the update stream'}")
+        clock_cold = shader_clock()
+        for _ in range(args.warmup):
+            pipe.submit(sym, out)
+        pipe.sync()
+        clock_before = shader_clock()
+        pipe.set_timing(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.submit(sym, out)
+        pipe.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_local = time.perf_counter() - t0
+        clock_after = shader_clock()
+        t_upd, t_cb, t_done = pipe.timing()
+        assert len(t_upd) == args.steps
+        upd_ms, cb_ms = float(np.mean(t_upd)), float(np.mean(t_cb))
+        step_times = np.diff(np.concatenate([[0.0], t_done.astype(np.float64)]))
 
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k, evs[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_local = time.perf_counter() - t0
+        def last_decisions(n):            # decision rows of the LAST timed step, straight from the pipeline's workspace
+            return pipe.export_last_decisions(n)
+    else:
+        # ---- A/B: the same schedule from Python.  Decision workspaces and HIP streams as vit_hip_pipeline_create picks them:
+        # update() is VALU-issue bound, chainback() is a latency/HBM-bound bit chase, so step i's chainback runs beside step
+        # i+1's update; a batch of at most one update wave per SIMD also gets a second update stream.
+        NWS = args.pipeline
+        NUPD = 1
+        if NWS == 0:
+            if dec.plan == _lib.PLAN_REG and F <= simds * tile_frames:
+                NWS, NUPD = 3, 2
+            elif dec.plan == _lib.PLAN_REG and F <= 2 * simds * tile_frames:
+                NWS = 2
+            else:
+                NWS = 1
+        wss = [dec.new_workspace(F, L) for _ in range(NWS)]
+        cb_prio = int(os.environ.get("VIT_BENCH_CB_PRIORITY", "-1"))  # high priority: the short bit chase gets out of the way of the update
+        s_upds = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(NUPD - 1)]
+        s_cb = torch.cuda.Stream(device=dev, priority=cb_prio) if NWS >= 2 else s_upds[0]
+        cb_done = [None] * NWS
+        sched_desc = f"python streams: {NWS} workspace(s), {NUPD} update stream(s), {'separate chainback stream' if NWS >= 2 else '1 stream'}"
+
+        def one_step(k, ev=None):
+            ws = wss[k % NWS]
+            s_upd = s_upds[k % NUPD]
+            if cb_done[k % NWS] is not None:
+                s_upd.wait_event(cb_done[k % NWS])          # the chainback that last read this workspace has finished
+            with torch.cuda.stream(s_upd):
+                if ev is not None:
+                    ev[0].record(s_upd)
+                dec.update(sym, L, want_metrics=False, workspace=ws)
+                upd_done = torch.cuda.Event(enable_timing=ev is not None) if ev is None else ev[1]
+                upd_done.record(s_upd)
+            s_cb.wait_event(upd_done)
+            with torch.cuda.stream(s_cb):
+                if ev is not None and NWS >= 2:
+                    ev[3].record(s_cb)
+                dec.chainback(F, L, out=out, workspace=ws)
+                done = torch.cuda.Event(enable_timing=ev is not None) if ev is None else ev[2]
+                done.record(s_cb)
+            cb_done[k % NWS] = done
+
+        clock_cold = shader_clock()
+        for k in range(args.warmup):
+            one_step(k)
+        torch.cuda.synchronize()
+        clock_before = shader_clock()
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.warmup + k, evs[k])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_local = time.perf_counter() - t0
+        clock_after = shader_clock()
+        upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        cb_ms = float(np.mean([(e[3] if NWS >= 2 else e[1]).elapsed_time(e[2]) for e in evs]))
+        t_done = np.asarray([evs[0][0].elapsed_time(e[2]) for e in evs], dtype=np.float64)
+        step_times = np.diff(np.concatenate([[0.0], t_done]))
+
+        def last_decisions(n):
+            return dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
+
     elapsed = elapsed_local
     per_rank = [float(F) * L * args.steps / elapsed_local / 1e6]
     if world > 1:
@@ -354,9 +440,6 @@ def main():
         rates = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
         dist.all_gather(rates, torch.tensor(per_rank, dtype=torch.float64, device=coll_dev))
         per_rank = [float(r.item()) for r in rates]
-
-    upd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    cb_ms = float(np.mean([(e[3] if NWS == 2 else e[1]).elapsed_time(e[2]) for e in evs]))
 
     # ---- size-independent parity property at full size: decoded bits vs transmitted bits ----
     lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
@@ -391,24 +474,36 @@ def main():
     result = {
         "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
         "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_ms, "ms_per_step_min": float(np.min(step_times)), "ms_per_step_median": float(np.median(step_times)),
+        "ms_per_step_max": float(np.max(step_times)), "ms_per_step_series": [round(float(x), 3) for x in step_times[:64]],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
         "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type} "
                                f"({'u16/s16' if sb == 2 else 'u8/s8'}), {F} frames x {L} info bits per GPU, "
                                f"AWGN Eb/N0={args.ebn0} dB", "frames_per_gpu": F, "bits_per_frame": L,
-                   "plan": _lib.PLAN_NAMES[dec.plan], "pipeline": f"{NWS} workspace(s), {'2 HIP streams' if NWS == 2 else '1 stream'}",
+                   "plan": _lib.PLAN_NAMES[dec.plan], "via": args.via, "pipeline": sched_desc,
                    "synth": args.synth,
                    "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
         "per_gpu_Mbit_s": value / world, "per_rank_Mbit_s": per_rank, "Msym_s": value * code.R,
         "ranks": {"world_size": world, "ranks_in_blob_allreduce": ranks_seen, "backend": args.backend if world > 1 else None,
                   "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world},
-        "update_ms": upd_ms, "chainback_ms": cb_ms,
+        "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
+        # the clock the SIMDs sustained under a packed-integer load right before / after the timed region (s_memtime against
+        # s_memrealtime around ~2 ms of v_pk_add_u16 on every SIMD: vit_hip_shader_clock_mhz), and the nominal maximum
+        "clock_mhz": {"before": clock_before[0], "after": clock_after[0], "before_warmup": clock_cold[0],
+                      "nominal_max_spec": CLOCK_GHZ * 1e3,
+                      "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]]},
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes,
+                     # `achieved` is per launch as the contract defines it.  With two update launches in flight (the small-batch
+                     # schedule) each one takes about twice as long while the SIMDs do the work of both: the kernel's rate over
+                     # the timed region, all launches together, is the second figure
+                     "launches_in_flight": NUPD,
+                     "achieved_all_launches_over_wall_clock": upd_bytes * args.steps / elapsed_local / 1e9,
                      "tighter_bound": "valu (roofline_valu below): the kernel's HBM bytes equal the algorithmic bytes and its "
                                       "waves issue packed integer VALU back to back (DESIGN.md 4.4)"},
-        # wall-clock of a whole step (the two kernels overlap on two streams when --pipeline 2, so their durations do not add)
+        # wall-clock of a whole step (the kernels overlap on separate streams where the schedule says so: durations do not add)
         "roofline_end_to_end": {"bound": "hbm", "achieved": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "bytes_per_info_bit": (upd_bytes + cb_bytes) / float(F * L)},
@@ -436,9 +531,8 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
-        # parity of the last timed step's results (workspace of step warmup+steps-1)
-        ws_last = wss[(args.warmup + args.steps - 1) % NWS]
-        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, dec, sym, out, ws_last, F, L)
+        # parity of the last timed step's results (the workspace that step wrote)
+        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, last_decisions, sym, out, F, L)
         result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         if "single_socket_extrapolated_Mbit_s" in result["cpu_baseline"]:
             result["speedup_vs_single_socket_extrapolated"] = value / result["cpu_baseline"]["single_socket_extrapolated_Mbit_s"]

@@ -13,8 +13,9 @@
  *   vit_hip_update_batch      reset() + Decoder::update<sum_t>()  viterbi_decoder_core.h:202-211, viterbi_decoder_scalar.h:29-55
  *   vit_hip_chainback_batch   chainback()                         viterbi_decoder_core.h:214-236
  *   vit_hip_decode_batch      the call pattern reset->update->chainback of examples/run_simple.cpp:76-80
- *   vit_hip_pipeline_*        the same pattern over a stream of batches, the two phases timed separately by the reference
- *                             (examples/run_benchmark.cpp:272-281) overlapped on two HIP streams
+ *   vit_hip_pipeline_*        the same pattern over a stream of batches (the benchmark's loop over frames,
+ *                             examples/run_benchmark.cpp:266-282, with its two separately timed phases :272-281) scheduled on
+ *                             two or three HIP streams; _set_timing/_get_timing report the two phases per batch
  *   vit_hip_update_host       update() on a host-resident Core (streaming, N = R allowed:
  *                                                                 examples/helpers/puncture_code_helpers.h:51)
  *   vit_hip_chainback_host    chainback() on host-resident decision rows
@@ -162,19 +163,46 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
 /* ---- double-buffered decode pipeline --------------------------------------------------------------------------------- */
 
 /* update() is bound by integer issue, chainback() by memory latency: run back to back they leave each other's resource
- * idle.  A pipeline owns two decision workspaces and two HIP streams and runs the chainback of batch i beside the update of
- * batch i+1 (the schedule bench.py measures: K = 7 soft16 4.15 -> 3.46 ms per 65536-frame batch).  submit() only enqueues
- * and returns; batches complete in order; the caller's symbol and output buffers of a batch must stay untouched until a
- * later sync() (or until `done_event`, an optional hipEvent_t passed as void*, has fired).
- * The overlap is applied where it pays -- the register plan with at most two update waves per SIMD (batches of up to
- * 2 x 4 x CUs x workspace_tile_frames frames: 65536 at K = 7, 9 on an MI355X); larger batches and the LDS plans fill the
- * CUs by themselves, a chainback in their way costs more than it hides, and submit() runs those back to back. */
+ * idle.  A pipeline owns the decision workspaces and HIP streams of a stream of batches and schedules them (this is what
+ * bench.py times).  submit() only enqueues and returns; batches complete in submit order; the caller's symbol and output
+ * buffers of a batch must stay untouched until a later sync() (or until `done_event`, an optional hipEvent_t passed as
+ * void*, has fired).  The schedule is fixed at create time from max_frames (vit_hip_pipeline_get_schedule reports it):
+ *   - register plan, more than one and at most two update waves per SIMD (4 x CUs x workspace_tile_frames < max_frames <=
+ *     2 x that: 65536 frames at K = 7, 9 on an MI355X): two workspaces, the chainback of batch i on a second, high-priority
+ *     stream beside the update of batch i+1 (K = 7 soft16: 4.15 -> 3.46 ms per 65536-frame batch);
+ *   - register plan, at most ONE update wave per SIMD (max_frames <= 4 x CUs x workspace_tile_frames: the 32768-frame share
+ *     of an 8-GPU run): THREE workspaces and TWO update streams, so that two update kernels share the SIMDs (a lone wave
+ *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream;
+ *   - larger batches and the LDS plans fill the CUs by themselves, a chainback in their way costs more than it hides:
+ *     one stream, update and chainback back to back. */
 typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
+typedef struct vit_hip_pipeline_schedule {
+    int32_t workspaces;             /* decision workspaces owned (2 or 3) */
+    int32_t update_streams;         /* update kernels that may be in flight at once (1 or 2) */
+    int32_t chainback_overlapped;   /* 1: chainbacks run on their own stream beside the next update; 0: back to back */
+    int32_t reserved;
+    size_t overlap_max_frames;      /* largest batch whose chainback is overlapped */
+    size_t two_updates_max_frames;  /* largest max_frames that gets the two-update schedule */
+    size_t workspace_bytes_each;
+} vit_hip_pipeline_schedule;
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
                             const uint32_t* d_end_state, void* done_event);
 int vit_hip_pipeline_sync(vit_hip_pipeline_t p);
 int vit_hip_pipeline_destroy(vit_hip_pipeline_t p);
+int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* schedule);
+/* the decision workspace of the most recently submitted batch (vit_hip_export_decisions reads the history from it): valid
+ * after a sync() and until the next submit(); owned by the pipeline. */
+int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace);
+/* Per-batch timing with HIP events on the streams the kernels run on (the reference times its two phases separately:
+ * examples/run_benchmark.cpp:272-281).  set_timing(p, 1) synchronises, clears the records and starts recording every
+ * submitted batch; set_timing(p, 0) stops.  get_timing() returns, for the batches completed by the last sync(), in submit
+ * order: the update kernel's duration, the chainback kernel's duration, and the time at which the batch's chainback finished
+ * measured from the start of the first recorded update (all in ms; consecutive differences of complete_ms are the
+ * pipeline's per-batch step times).  Arrays may be NULL; at most `capacity` entries are written, *n_batches is the count. */
+int vit_hip_pipeline_set_timing(vit_hip_pipeline_t p, int enable);
+int vit_hip_pipeline_get_timing(vit_hip_pipeline_t p, size_t capacity, float* update_ms, float* chainback_ms, float* complete_ms,
+                                size_t* n_batches);
 
 /* ---- batched streaming: a batch of decoders fed in chunks, state resident on the device ------------------------- */
 
@@ -219,6 +247,13 @@ int vit_hip_synth_batch(vit_hip_handle h, size_t frames, size_t L, uint64_t seed
 /* *d_count (uint64, device) += number of differing bits between two device byte arrays. */
 int vit_hip_count_bit_errors(vit_hip_handle h, const uint8_t* d_a, const uint8_t* d_b, size_t n_bytes, uint64_t* d_count,
                              vit_hip_stream_t stream);
+
+/* The clock the SIMDs sustain under the update kernels' instruction class, measured on the device: every SIMD runs four waves
+ * of independent v_pk_add_u16 for about 2 ms between readings of s_memtime (shader clocks) and s_memrealtime (constant
+ * reference clock); *mhz_out = their median ratio x the reference rate.  *cycles_per_pk_instr_out (may be NULL) = shader
+ * clocks one SIMD needed per wave64 packed instruction in that loop.  Synchronous; measurement harness (bench.py quotes its
+ * VALU ceiling at this clock, not at a nominal one). */
+int vit_hip_shader_clock_mhz(int device, double* mhz_out, double* cycles_per_pk_instr_out);
 
 /* ---- host-pointer compatibility route (one decoder object, streaming) ------------------------------------------ */
 

@@ -122,6 +122,22 @@ public:
     void sync() {
         if (vit_hip_pipeline_sync(m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_sync");
     }
+    // which schedule the library chose for max_frames: workspaces, update kernels in flight, chainback overlap
+    vit_hip_pipeline_schedule schedule() const {
+        vit_hip_pipeline_schedule s;
+        if (vit_hip_pipeline_get_schedule(m_pipe, &s) != VIT_HIP_OK) die("vit_hip_pipeline_get_schedule");
+        return s;
+    }
+    // per-batch kernel durations (HIP events on the kernels' own streams), the way the reference times update and chainback
+    // separately (examples/run_benchmark.cpp:272-281); see vit_hip_pipeline_get_timing
+    void set_timing(bool enable) {
+        if (vit_hip_pipeline_set_timing(m_pipe, enable ? 1 : 0) != VIT_HIP_OK) die("vit_hip_pipeline_set_timing");
+    }
+    size_t timing(size_t capacity, float* update_ms, float* chainback_ms, float* complete_ms) const {
+        size_t n = 0;
+        if (vit_hip_pipeline_get_timing(m_pipe, capacity, update_ms, chainback_ms, complete_ms, &n) != VIT_HIP_OK) die("vit_hip_pipeline_get_timing");
+        return n;
+    }
 
 private:
     static void die(const char* what) {

@@ -202,25 +202,39 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
             assert np.array_equal(dec.decode(view, L).cpu().numpy(), want), (off, plan)
 
 
-@pytest.mark.parametrize("code_id,F,L", [(2, 2048, 1024),     # register plan, small batch: chainback beside the next update
-                                         (7, 24, 256)])       # K = 15 (PLAN_LDS2): submit() runs the two back to back
-def test_decode_pipeline_matches_serial_decode(code_id, F, L):
-    """vit_hip_pipeline_*: the double-buffered schedule (chainback of batch i beside the update of batch i+1, where that
-    pays) returns the bytes of the serial vit_hip_decode_batch for every batch, including batches smaller than the
-    pipeline's maximum."""
+@pytest.mark.parametrize("code_id,decode_type,F,L,want", [
+    (2, "SOFT16", 2048, 1024, (3, 2, 1)),    # register plan, at most one update wave per SIMD: three workspaces, two updates in flight
+    (2, "HARD8", 32768, 256, (3, 2, 1)),     # the largest batch of that schedule on an MI355X (4 x 256 CUs x 32 frames)
+    (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
+    (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
+    (7, "SOFT16", 24, 256, (2, 1, 0)),       # K = 15 (PLAN_LDS2): back to back
+])
+def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want):
+    """vit_hip_pipeline_*: whatever schedule the library picks (two updates in flight, chainback beside the next update, or
+    back to back) every batch returns the bytes of the serial vit_hip_decode_batch, including batches smaller than the
+    pipeline's maximum and more batches than workspaces; the per-batch timing records line up with the submissions."""
     import ctypes as C
     import torch
 
     code = COMMON_CODES[code_id]
-    pc, table, config = make_table_config(code, "SOFT16")
+    pc, table, config = make_table_config(code, decode_type)
     dec = BatchDecoder(table, config)
     lib = _lib.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus != 256 and code_id == 2:
+        want = None                              # the thresholds scale with the CU count: only the results are checked
     pipe = C.c_void_p()
     assert lib.vit_hip_pipeline_create(dec._handle._h, F, L, C.byref(pipe)) == _lib.OK
+    sch = _lib.VitHipPipelineSchedule()
+    assert lib.vit_hip_pipeline_get_schedule(pipe, C.byref(sch)) == _lib.OK
+    if want is not None:
+        assert (sch.workspaces, sch.update_streams, sch.chainback_overlapped) == want
+    assert sch.workspace_bytes_each == dec.workspace_bytes(F, L)
+    assert lib.vit_hip_pipeline_set_timing(pipe, 1) == _lib.OK
     batches, outs = [], []
-    for k in range(5):
+    for k in range(7):
         n = F if k != 3 else max(F // 3, 1)
-        tx, sym = dec.synth(n, L, 2.0, seed=50 + k)
+        tx, sym = dec.synth(n, L, 4.0 if decode_type == "HARD8" else 2.0, seed=50 + k)
         out = torch.zeros((n, L // 8), dtype=torch.uint8, device="cuda")
         batches.append((n, sym, tx))
         outs.append(out)
@@ -231,13 +245,39 @@ def test_decode_pipeline_matches_serial_decode(code_id, F, L):
     assert lib.vit_hip_pipeline_sync(pipe) == _lib.OK
     for (n, sym, tx), out in zip(batches, outs):
         assert torch.equal(out, dec.decode(sym, L))
+    # the last batch's decision rows are readable from the pipeline's own workspace
+    ws = C.c_void_p()
+    assert lib.vit_hip_pipeline_last_workspace(pipe, C.byref(ws)) == _lib.OK
+    n_last = min(batches[-1][0], 64)
+    got = torch.empty((n_last, L + code.K - 1, dec.W), dtype=torch.int64, device="cuda")
+    assert lib.vit_hip_export_decisions(dec._handle._h, ws, n_last, L + code.K - 1, L, C.c_void_p(got.data_ptr()), None) == _lib.OK
+    dec.update(batches[-1][1], L)
+    assert torch.equal(got, dec.export_decisions(n_last, L))
+    # timing: one record per batch, in order, completion times non-decreasing
+    nrec = C.c_size_t(0)
+    u, c, d = (np.zeros(16, dtype=np.float32) for _ in range(3))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert lib.vit_hip_pipeline_get_timing(pipe, 16, p(u), p(c), p(d), C.byref(nrec)) == _lib.OK
+    assert nrec.value == len(batches)
+    assert (u[:7] > 0).all() and (c[:7] > 0).all() and (np.diff(d[:7]) >= 0).all() and d[0] >= u[0]
+    assert lib.vit_hip_pipeline_set_timing(pipe, 0) == _lib.OK
+    assert lib.vit_hip_pipeline_get_timing(pipe, 0, None, None, None, C.byref(nrec)) == _lib.OK and nrec.value == 0
     assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK
 
 
+def test_shader_clock_measurement():
+    import ctypes as C
+
+    mhz, cyc = C.c_double(0), C.c_double(0)
+    assert _lib.load().vit_hip_shader_clock_mhz(0, C.byref(mhz), C.byref(cyc)) == _lib.OK
+    assert 500.0 < mhz.value < 3000.0, mhz.value          # MI355X: 2400 MHz peak engine clock
+    assert 1.0 < cyc.value < 16.0, cyc.value              # shader clocks per wave64 v_pk_add_u16 and SIMD, four waves resident
+
+
 @pytest.mark.parametrize("K,R,G,plan,F,L", [
-    (10, 2, (0o1167, 0o1545), _lib.PLAN_LDS, 7, 100),     # dense [F][S][W]: slab stride 109 * 8 * 8 = 6976 B, not a multiple of 256
-    (6, 2, (0o65, 0o57), _lib.PLAN_LDS, 9, 33),           # W = 1: 304-byte slabs
-    (7, 2, (109, 79), _lib.PLAN_REG, 70, 100),            # 32-frame tiles
+    (10, 2, (0o1167, 0o1545), _lib.PLAN_LDS, 7, 104),     # dense [F][S][W]: slab stride 113 * 8 * 8 = 7232 B, not a multiple of 256
+    (6, 2, (0o65, 0o57), _lib.PLAN_LDS, 9, 40),           # W = 1: 360-byte slabs
+    (7, 2, (109, 79), _lib.PLAN_REG, 70, 104),            # 32-frame tiles
     (11, 2, (0o3345, 0o3613), _lib.PLAN_LDS2, 7, 40),     # frame pairs
 ])
 def test_slab_sub_range_export_and_chainback(oracle, K, R, G, plan, F, L):

@@ -70,3 +70,33 @@ def test_single_rank_line_is_self_consistent():
         assert cb["per_thread_Mbit_s"] * 2 > cb["simd_1thread_Mbit_s"]
     par = r["parity"]
     assert par["bit_exact"] and par["decision_words_bit_exact"] and par["chainback_bytes_bit_exact"]
+    assert r["config"]["via"] == "pipeline" and "vit_hip_pipeline" in r["config"]["pipeline"]
+    assert r["ms_per_step_min"] <= r["ms_per_step_median"] <= r["ms_per_step_max"]
+    assert 500 < r["clock_mhz"]["before"] < 3000 and 500 < r["clock_mhz"]["after"] < 3000
+
+
+@pytest.mark.gpu
+def test_headline_line_carries_its_spread_and_both_routes_agree():
+    """the default workload (BASELINE configs[1]) through the shipped pipeline API: the per-step times recorded on the device
+    bracket their median, the median agrees with the wall-clock figure, and the Python re-implementation of the schedule
+    (--via python) lands on the same rate."""
+    a = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"))
+    assert a["config"]["frames_per_gpu"] == 65536 and a["config"]["bits_per_frame"] == 8192 and a["config"]["via"] == "pipeline"
+    assert a["ms_per_step_min"] <= a["ms_per_step_median"] <= a["ms_per_step_max"]
+    # wall clock over the timed region = the steady step (the median) + one pipeline fill and drain (the first update has no
+    # chainback beside it, the last chainback no update: about one millisecond over the 20 steps) + the first steps' run-in
+    assert abs(a["ms_per_step_median"] - a["ms_per_step"]) / a["ms_per_step"] < 0.05, a
+    assert len(a["ms_per_step_series"]) == 20 and abs(sum(a["ms_per_step_series"]) / 20 - a["ms_per_step"]) < 0.05 * a["ms_per_step"]
+    b = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--via", "python"))
+    assert b["config"]["via"] == "python"
+    assert abs(a["value"] - b["value"]) / b["value"] < 0.03, (a["value"], b["value"])
+
+
+@pytest.mark.gpu
+def test_config_presets_name_the_baseline_configs():
+    """--config 3 is one GPU's share of the 8-GPU hard-decision run; the small-batch schedule (two updates in flight) serves it"""
+    r = _json_line(_run("--config", "3", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"))
+    assert r["dtype"] == "u8" and r["config"]["frames_per_gpu"] == 32768 and r["config"]["bits_per_frame"] == 8192
+    assert "HARD8" in r["config"]["workload"]
+    assert r["update_launches_in_flight"] == 2 and r["roofline"]["launches_in_flight"] == 2
+    assert 0 < r["ber"] < 1e-2

@@ -24,8 +24,8 @@ EXPORTS = [
     "vit_hip_workspace_bytes", "vit_hip_workspace_slab_bytes", "vit_hip_update_batch", "vit_hip_chainback_batch", "vit_hip_decode_batch",
     "vit_hip_export_decisions", "vit_hip_depuncture_batch", "vit_hip_update_host", "vit_hip_chainback_host",
     "vit_hip_reset_batch", "vit_hip_update_batch_resume", "vit_hip_broadcast_table", "vit_hip_synth_batch",
-    "vit_hip_count_bit_errors", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
-    "vit_hip_pipeline_destroy",
+    "vit_hip_count_bit_errors", "vit_hip_shader_clock_mhz", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
+    "vit_hip_pipeline_destroy", "vit_hip_pipeline_get_schedule", "vit_hip_pipeline_last_workspace", "vit_hip_pipeline_set_timing", "vit_hip_pipeline_get_timing",
 ]
 
 
@@ -34,6 +34,12 @@ class VitHipInfo(C.Structure):
                 ("num_states", C.c_int32), ("decision_words", C.c_int32), ("device", C.c_int32), ("plan", C.c_int32),
                 ("soft_decision_high", C.c_int32), ("soft_decision_low", C.c_int32), ("polynomials", C.c_uint32 * 16),
                 ("table_is_linear", C.c_int32), ("workspace_tile_frames", C.c_int32)]
+
+
+class VitHipPipelineSchedule(C.Structure):
+    _fields_ = [("workspaces", C.c_int32), ("update_streams", C.c_int32), ("chainback_overlapped", C.c_int32),
+                ("reserved", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
+                ("workspace_bytes_each", C.c_size_t)]
 
 
 class VitHipError(RuntimeError):
@@ -83,10 +89,15 @@ def load():
     L.vit_hip_broadcast_table.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     L.vit_hip_synth_batch.argtypes = [vp, sz, sz, C.c_uint64, C.c_uint64, C.c_float, i32, vp, vp, vp]
     L.vit_hip_count_bit_errors.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.vit_hip_shader_clock_mhz.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.vit_hip_pipeline_create.argtypes = [vp, sz, sz, C.POINTER(vp)]
     L.vit_hip_pipeline_submit.argtypes = [vp, vp, sz, vp, vp, vp]
     L.vit_hip_pipeline_sync.argtypes = [vp]
     L.vit_hip_pipeline_destroy.argtypes = [vp]
+    L.vit_hip_pipeline_get_schedule.argtypes = [vp, C.POINTER(VitHipPipelineSchedule)]
+    L.vit_hip_pipeline_last_workspace.argtypes = [vp, C.POINTER(vp)]
+    L.vit_hip_pipeline_set_timing.argtypes = [vp, i32]
+    L.vit_hip_pipeline_get_timing.argtypes = [vp, sz, vp, vp, vp, C.POINTER(sz)]
     L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     L.vit_hip_chainback_host.argtypes = [vp, vp, sz, sz, vp]
     _lib = L

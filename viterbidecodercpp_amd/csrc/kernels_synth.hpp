@@ -164,4 +164,34 @@ __global__ void __launch_bounds__(256) bit_errors_kernel(BitErrArgs a) {
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(a.count, acc);
 }
 
+// ---- the shader clock under a packed-integer load (measurement harness) -----------------------------------------------
+// Every wave runs `iters` rounds of 64 independent v_pk_add_u16 (the update kernels' instruction class) and brackets them with
+// s_memtime (counts shader-core clocks) and s_memrealtime (counts a constant reference clock, hipDeviceAttributeWallClockRate):
+// their ratio is the clock the SIMDs actually ran at while loaded the way the update kernels load them -- the number a
+// cycles-per-instruction ceiling has to be multiplied with.  out[wave] = {shader clocks, reference clocks}.
+__global__ void __launch_bounds__(256) shader_clock_kernel(uint64_t* out, uint32_t iters, uint32_t seed) {
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = seed + threadIdx.x * 16u + (uint32_t)i;
+    const uint32_t inc = seed | 0x00010001u;
+    const uint64_t c0 = __builtin_readcyclecounter();          // s_memtime
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t k = 0; k < iters; ++k) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(v[i]) : "v"(inc));
+    }
+    const uint64_t c1 = __builtin_readcyclecounter();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x ^= v[i];
+    if ((threadIdx.x & 63u) == 0) {
+        const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        out[2 * w] = (c1 - c0) + (x == 0x12345u ? 1u : 0u);   // keeps the adds alive
+        out[2 * w + 1] = r1 - r0;
+    }
+}
+
 }  // namespace vit

@@ -9,6 +9,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -607,17 +608,40 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
 struct vit_hip_pipeline {
     vit_hip_handle h = nullptr;
     size_t max_frames = 0, L = 0, ws_bytes = 0;
-    void* ws[2] = {nullptr, nullptr};
-    hipStream_t s_upd = nullptr, s_cb = nullptr;
-    hipEvent_t upd_done[2] = {nullptr, nullptr}, cb_done[2] = {nullptr, nullptr};
-    bool cb_pending[2] = {false, false};
+    // schedule (fixed at create time from max_frames): n_ws decision workspaces used round robin, n_upd update streams
+    int n_ws = 2, n_upd = 1;
+    void* ws[3] = {nullptr, nullptr, nullptr};
+    hipStream_t s_upd[2] = {nullptr, nullptr}, s_cb = nullptr;
+    hipEvent_t upd_done[3] = {nullptr, nullptr, nullptr}, cb_done[3] = {nullptr, nullptr, nullptr};
+    bool cb_pending[3] = {false, false, false};
     unsigned long long n = 0;
-    size_t overlap_max_frames = 0;   // largest batch whose chainback is worth running beside the next update
+    size_t overlap_max_frames = 0;      // largest batch whose chainback is worth running beside the next update
+    size_t two_updates_max_frames = 0;  // largest batch that leaves room for a second update kernel beside the first
+    // optional per-batch timing (vit_hip_pipeline_set_timing): four events per submitted batch, resolved by sync()
+    bool timing = false;
+    struct Rec { hipEvent_t u0, u1, c0, c1; };
+    std::vector<Rec> pending_recs;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<float> t_update, t_chainback, t_complete;   // ms; t_complete: end of the batch's chainback since epoch
+    hipEvent_t epoch = nullptr;          // start of the first timed batch's update
 };
+
+namespace {
+hipEvent_t pipe_event(vit_hip_pipeline* p) {
+    if (!p->event_pool.empty()) {
+        hipEvent_t e = p->event_pool.back();
+        p->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
 
 extern "C" {
 
-int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
+static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
     if (!h || !out || max_frames == 0) return fail(VIT_HIP_ERR_INVALID_ARG, "bad pipeline arguments");
     *out = nullptr;
     DeviceGuard guard(h->device);
@@ -626,52 +650,80 @@ int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_h
     if (!p) return fail(VIT_HIP_ERR_RUNTIME, "out of host memory");
     p->h = h; p->max_frames = max_frames; p->L = L;
     p->ws_bytes = vit_hip_workspace_bytes(h, max_frames, L);
-    // The overlap pays while the update leaves register file and issue slots free: PLAN_REG with at most two update waves per
-    // SIMD (a 140-register wave; the chainback's 166 make a third resident).  A larger batch fills the SIMDs by itself, and
-    // the PLAN_LDS2 / PLAN_LDS update takes whole CUs: there a chainback in the way only costs (measured: K7 131072 frames
-    // 8.70 ms overlapped vs 8.10 ms back to back; K15 55.1 vs 54.8), so those batches run back to back on one stream.
+    // Rule 1 -- chainback beside the next update.  The overlap pays while the update leaves register file and issue slots
+    // free: PLAN_REG with at most two update waves per SIMD (a 140-register wave; the chainback's 166 make a third resident).
+    // A larger batch fills the SIMDs by itself, and the PLAN_LDS2 / PLAN_LDS update takes whole CUs: there a chainback in the
+    // way only costs (measured: K7 131072 frames 8.70 ms overlapped vs 8.10 ms back to back; K15 55.1 vs 54.8), so those
+    // batches run back to back on one stream.
+    // Rule 2 -- two updates in flight.  A batch of at most ONE update wave per SIMD (frames <= 4 x CUs x tile: the 32768-frame
+    // share of BASELINE configs[3]) issues at the one-wave rate (5.27 cycles per packed instruction against 4.52 with two
+    // waves, profiles/r2_dep_rate.txt): a second update stream and a third workspace put the next batch's update beside it
+    // (hard8 32768 x 8192: 2.01 -> 1.87 ms per batch, scripts/exp_pipeline3.py).
     {
         int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-        p->overlap_max_frames = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)2 * 4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
+        const size_t per_wave = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
+        p->overlap_max_frames = 2 * per_wave;
+        p->two_updates_max_frames = per_wave;
+        const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
+        if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
     }
+    p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
+    p->n_ws = p->n_upd + 1;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
-    bool ok = hipStreamCreateWithFlags(&p->s_upd, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithPriority(&p->s_cb, hipStreamNonBlocking, hi) == hipSuccess;   // the short bit chase gets out of the update's way
-    for (int k = 0; k < 2 && ok; ++k)
+    bool ok = hipStreamCreateWithPriority(&p->s_cb, hipStreamNonBlocking, hi) == hipSuccess;   // the short bit chase gets out of the update's way
+    for (int k = 0; k < p->n_upd && ok; ++k) ok = hipStreamCreateWithFlags(&p->s_upd[k], hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < p->n_ws && ok; ++k)
         ok = hipMalloc(&p->ws[k], p->ws_bytes) == hipSuccess &&
              hipEventCreateWithFlags(&p->upd_done[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&p->cb_done[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)vit_hip_pipeline_destroy(p);
-        return fail(VIT_HIP_ERR_RUNTIME, "pipeline allocation failed (two decision workspaces of vit_hip_workspace_bytes each)");
+        return fail(VIT_HIP_ERR_RUNTIME, "pipeline allocation failed (two or three decision workspaces of vit_hip_workspace_bytes each)");
     }
     *out = p;
     return VIT_HIP_OK;
 }
 
-int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
+static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
                             const uint32_t* d_end_state, void* done_event) {
     if (!p) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL pipeline");
     if (frames > p->max_frames) return fail(VIT_HIP_ERR_INVALID_ARG, "batch larger than the pipeline was created for");
     if (frames == 0) return VIT_HIP_OK;
     DeviceGuard guard(p->h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
-    const int k = (int)(p->n & 1ull);
+    const int k = (int)(p->n % (unsigned long long)p->n_ws);
+    hipStream_t s_upd = p->s_upd[(int)(p->n % (unsigned long long)p->n_upd)];
+    vit_hip_pipeline::Rec rec{nullptr, nullptr, nullptr, nullptr};
+    if (p->timing) {
+        rec.u0 = pipe_event(p); rec.u1 = pipe_event(p); rec.c0 = pipe_event(p); rec.c1 = pipe_event(p);
+        if (!rec.u0 || !rec.u1 || !rec.c0 || !rec.c1) return fail(VIT_HIP_ERR_RUNTIME, "hipEventCreate failed");
+    }
     // the chainback that last read this workspace must have finished before the update overwrites it
-    if (p->cb_pending[k]) VIT_HIP_CHECK(hipStreamWaitEvent(p->s_upd, p->cb_done[k], 0));
+    if (p->cb_pending[k]) VIT_HIP_CHECK(hipStreamWaitEvent(s_upd, p->cb_done[k], 0));
+    if (p->timing) {
+        VIT_HIP_CHECK(hipEventRecord(rec.u0, s_upd));
+        if (!p->epoch) p->epoch = rec.u0;
+    }
     int rc = vit_hip_update_batch(p->h, d_symbols, frames, p->L + (size_t)p->h->K - 1, p->L, p->ws[k], p->ws_bytes, nullptr, nullptr,
-                                  nullptr, p->s_upd);
+                                  nullptr, s_upd);
     if (rc != VIT_HIP_OK) return rc;
-    hipStream_t s_cb = p->s_upd;                                // back to back unless the overlap pays (pipeline_create)
-    if (frames <= p->overlap_max_frames) {
+    if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.u1, s_upd));
+    hipStream_t s_cb = s_upd;                                   // back to back unless the overlap pays (pipeline_create)
+    if (frames <= p->overlap_max_frames || p->n_upd > 1) {
+        // all chainbacks go through ONE stream: batches complete in submit order whichever update stream fed them
         s_cb = p->s_cb;
-        VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], p->s_upd));
+        VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], s_upd));
         VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
     }
+    if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
     rc = vit_hip_chainback_batch(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, s_cb);
     if (rc != VIT_HIP_OK) return rc;
+    if (p->timing) {
+        VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
+        p->pending_recs.push_back(rec);
+    }
     VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], s_cb));
     if (done_event) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, s_cb));
     p->cb_pending[k] = true;
@@ -679,26 +731,91 @@ int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t 
     return VIT_HIP_OK;
 }
 
-int vit_hip_pipeline_sync(vit_hip_pipeline_t p) {
+static int vit_hip_pipeline_sync_impl(vit_hip_pipeline_t p) {
     if (!p) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL pipeline");
     DeviceGuard guard(p->h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
-    VIT_HIP_CHECK(hipStreamSynchronize(p->s_upd));
+    for (int k = 0; k < p->n_upd; ++k) VIT_HIP_CHECK(hipStreamSynchronize(p->s_upd[k]));
     VIT_HIP_CHECK(hipStreamSynchronize(p->s_cb));
+    // resolve the timing records of the batches that have now completed
+    for (const auto& r : p->pending_recs) {
+        float u = 0.f, c = 0.f, d = 0.f;
+        VIT_HIP_CHECK(hipEventElapsedTime(&u, r.u0, r.u1));
+        VIT_HIP_CHECK(hipEventElapsedTime(&c, r.c0, r.c1));
+        VIT_HIP_CHECK(hipEventElapsedTime(&d, p->epoch, r.c1));
+        p->t_update.push_back(u); p->t_chainback.push_back(c); p->t_complete.push_back(d);
+    }
+    for (const auto& r : p->pending_recs) {
+        if (r.u0 != p->epoch) p->event_pool.push_back(r.u0);
+        p->event_pool.push_back(r.u1); p->event_pool.push_back(r.c0); p->event_pool.push_back(r.c1);
+    }
+    p->pending_recs.clear();
+    return VIT_HIP_OK;
+}
+
+static int vit_hip_pipeline_set_timing_impl(vit_hip_pipeline_t p, int enable) {
+    if (!p) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL pipeline");
+    const int rc = vit_hip_pipeline_sync_impl(p);               // nothing in flight while the records are reset
+    if (rc != VIT_HIP_OK) return rc;
+    p->t_update.clear(); p->t_chainback.clear(); p->t_complete.clear();
+    if (p->epoch) { p->event_pool.push_back(p->epoch); p->epoch = nullptr; }
+    p->timing = enable != 0;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_get_timing(vit_hip_pipeline_t p, size_t capacity, float* update_ms, float* chainback_ms, float* complete_ms,
+                                size_t* n_batches) {
+    if (!p || !n_batches) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    const size_t n = p->t_update.size();
+    *n_batches = n;
+    for (size_t i = 0; i < n && i < capacity; ++i) {
+        if (update_ms) update_ms[i] = p->t_update[i];
+        if (chainback_ms) chainback_ms[i] = p->t_chainback[i];
+        if (complete_ms) complete_ms[i] = p->t_complete[i];
+    }
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace) {
+    if (!p || !d_workspace) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    if (p->n == 0) return fail(VIT_HIP_ERR_INVALID_ARG, "no batch has been submitted");
+    *d_workspace = p->ws[(int)((p->n - 1) % (unsigned long long)p->n_ws)];
+    return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* s) {
+    if (!p || !s) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    memset(s, 0, sizeof(*s));
+    s->workspaces = p->n_ws;
+    s->update_streams = p->n_upd;
+    s->chainback_overlapped = (p->n_upd > 1 || p->max_frames <= p->overlap_max_frames) ? 1 : 0;
+    s->overlap_max_frames = p->overlap_max_frames;
+    s->two_updates_max_frames = p->two_updates_max_frames;
+    s->workspace_bytes_each = p->ws_bytes;
     return VIT_HIP_OK;
 }
 
 int vit_hip_pipeline_destroy(vit_hip_pipeline_t p) {
     if (!p) return VIT_HIP_OK;
     DeviceGuard guard(p->h->device);
-    if (p->s_upd) (void)hipStreamSynchronize(p->s_upd);
+    for (int k = 0; k < 2; ++k)
+        if (p->s_upd[k]) (void)hipStreamSynchronize(p->s_upd[k]);
     if (p->s_cb) (void)hipStreamSynchronize(p->s_cb);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (p->ws[k]) (void)hipFree(p->ws[k]);
         if (p->upd_done[k]) (void)hipEventDestroy(p->upd_done[k]);
         if (p->cb_done[k]) (void)hipEventDestroy(p->cb_done[k]);
     }
-    if (p->s_upd) (void)hipStreamDestroy(p->s_upd);
+    for (const auto& r : p->pending_recs) {
+        if (r.u0 && r.u0 != p->epoch) (void)hipEventDestroy(r.u0);
+        if (r.u1) (void)hipEventDestroy(r.u1);
+        if (r.c0) (void)hipEventDestroy(r.c0);
+        if (r.c1) (void)hipEventDestroy(r.c1);
+    }
+    if (p->epoch) (void)hipEventDestroy(p->epoch);
+    for (hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k)
+        if (p->s_upd[k]) (void)hipStreamDestroy(p->s_upd[k]);
     if (p->s_cb) (void)hipStreamDestroy(p->s_cb);
     delete p;
     return VIT_HIP_OK;
@@ -862,6 +979,42 @@ int vit_hip_count_bit_errors(vit_hip_handle h, const uint8_t* d_a, const uint8_t
     return VIT_HIP_OK;
 }
 
+static int vit_hip_shader_clock_mhz_impl(int device, double* mhz_out, double* cycles_per_pk_instr_out) {
+    if (!mhz_out) return fail(VIT_HIP_ERR_INVALID_ARG, "mhz_out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VIT_HIP_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(VIT_HIP_ERR_INVALID_ARG, "device index out of range");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    int cus = 0, wall_khz = 0;
+    VIT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+    // four waves on every SIMD of the chip (one 256-thread workgroup per SIMD), about 2 ms of packed adds at 2.4 GHz
+    const unsigned blocks = (unsigned)(cus > 0 ? cus : 256) * 4u, iters = 4000;
+    const size_t waves = (size_t)blocks * 4;
+    uint64_t* d_out = nullptr;
+    VIT_HIP_CHECK(hipMalloc((void**)&d_out, waves * 2 * sizeof(uint64_t)));
+    std::vector<uint64_t> host(waves * 2);
+    hipLaunchKernelGGL(vit::shader_clock_kernel, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 3u);
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpy(host.data(), d_out, waves * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(VIT_HIP_ERR_RUNTIME, "shader clock kernel failed");
+    std::vector<double> ratio, cyc;
+    for (size_t w = 0; w < waves; ++w)
+        if (host[2 * w + 1] > 0) {
+            ratio.push_back((double)host[2 * w] / (double)host[2 * w + 1]);
+            cyc.push_back((double)host[2 * w] / ((double)iters * 64.0));
+        }
+    if (ratio.empty()) return fail(VIT_HIP_ERR_RUNTIME, "shader clock kernel returned no samples");
+    std::sort(ratio.begin(), ratio.end());
+    std::sort(cyc.begin(), cyc.end());
+    *mhz_out = ratio[ratio.size() / 2] * (double)wall_khz / 1000.0;
+    // four waves share a SIMD: the SIMD issues one of these instructions every (wave cycles per instruction) / 4
+    if (cycles_per_pk_instr_out) *cycles_per_pk_instr_out = cyc[cyc.size() / 2] / 4.0;
+    return VIT_HIP_OK;
+}
+
 int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps,
                         uint64_t* decisions_out, uint64_t* renorm_sum_out) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
@@ -961,6 +1114,27 @@ int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vi
 
 int vit_hip_set_plan(vit_hip_handle h, int plan) {
     VIT_HIP_NOTHROW(return vit_hip_set_plan_impl(h, plan));
+}
+
+int vit_hip_shader_clock_mhz(int device, double* mhz_out, double* cycles_per_pk_instr_out) {
+    VIT_HIP_NOTHROW(return vit_hip_shader_clock_mhz_impl(device, mhz_out, cycles_per_pk_instr_out));
+}
+
+int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_create_impl(h, max_frames, L, out));
+}
+
+int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, void* done_event) {
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_submit_impl(p, d_symbols, frames, d_bytes_out, d_end_state, done_event));
+}
+
+int vit_hip_pipeline_sync(vit_hip_pipeline_t p) {
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_sync_impl(p));
+}
+
+int vit_hip_pipeline_set_timing(vit_hip_pipeline_t p, int enable) {
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_set_timing_impl(p, enable));
 }
 
 int vit_hip_broadcast_table(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,

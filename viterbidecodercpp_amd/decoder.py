@@ -428,3 +428,64 @@ class BatchDecoder:
         _lib.check(_lib.load().vit_hip_export_decisions(self._handle._h, C.c_void_p(ws.data_ptr()), frames, n_steps, L,
                                                         C.c_void_p(dec.data_ptr()), self._stream()))
         return dec
+
+
+class DecodePipeline:
+    """vit_hip_pipeline_*: a stream of batches through one decoder, scheduled by the library (chainback of batch i beside the
+    update of batch i+1, two updates in flight for small batches -- include/vit_hip.h).  The Python face of the C++
+    ViterbiDecoder_HIP_Pipeline (include/viterbi_hip/viterbi_decoder_hip_batch.h); the loop it replaces is the reference
+    benchmark's per-frame reset -> update -> chainback (examples/run_benchmark.cpp:266-282)."""
+
+    def __init__(self, decoder: BatchDecoder, max_frames: int, L: int):
+        self.decoder, self.max_frames, self.L = decoder, int(max_frames), int(L)
+        self._p = C.c_void_p()
+        with decoder.torch.cuda.device(decoder.device):
+            _lib.check(_lib.load().vit_hip_pipeline_create(decoder._handle._h, self.max_frames, self.L, C.byref(self._p)))
+        self.schedule = _lib.VitHipPipelineSchedule()
+        _lib.check(_lib.load().vit_hip_pipeline_get_schedule(self._p, C.byref(self.schedule)))
+
+    def submit(self, symbols, out, end_state=None):
+        """enqueue one batch: symbols [F][L+K-1][R] -> out [F][L/8]; both must stay untouched until sync()"""
+        frames = self.decoder._check_symbols(symbols, self.L + self.decoder.K - 1)
+        if out.dtype != self.decoder.torch.uint8 or not out.is_contiguous() or out.numel() != frames * ((self.L + 7) // 8):
+            raise ValueError("out must be a contiguous uint8 tensor [frames][ceil(L/8)]")
+        _lib.check(_lib.load().vit_hip_pipeline_submit(self._p, C.c_void_p(symbols.data_ptr()), frames, C.c_void_p(out.data_ptr()),
+                                                       C.c_void_p(end_state.data_ptr()) if end_state is not None else None, None))
+
+    def sync(self):
+        _lib.check(_lib.load().vit_hip_pipeline_sync(self._p))
+
+    def export_last_decisions(self, frames: int, n_steps: int = None):
+        """decision rows [frames][n_steps][W] of the most recently submitted batch (after sync())"""
+        dec, t = self.decoder, self.decoder.torch
+        n_steps = (self.L + dec.K - 1) if n_steps is None else n_steps
+        ws = C.c_void_p()
+        _lib.check(_lib.load().vit_hip_pipeline_last_workspace(self._p, C.byref(ws)))
+        out = t.empty((frames, n_steps, dec.W), dtype=t.int64, device=dec.device)
+        _lib.check(_lib.load().vit_hip_export_decisions(dec._handle._h, ws, frames, n_steps, self.L, C.c_void_p(out.data_ptr()),
+                                                        dec._stream()))
+        return out
+
+    def set_timing(self, enable: bool):
+        _lib.check(_lib.load().vit_hip_pipeline_set_timing(self._p, 1 if enable else 0))
+
+    def timing(self):
+        """(update_ms, chainback_ms, complete_ms) float32 arrays, one entry per batch completed since set_timing(True)"""
+        L = _lib.load()
+        n = C.c_size_t(0)
+        _lib.check(L.vit_hip_pipeline_get_timing(self._p, 0, None, None, None, C.byref(n)))
+        u, c, d = (np.zeros(n.value, dtype=np.float32) for _ in range(3))
+        _lib.check(L.vit_hip_pipeline_get_timing(self._p, n.value, u.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                                                 d.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return u, c, d
+
+    def close(self):
+        if getattr(self, "_p", None):
+            _lib.load().vit_hip_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
