@@ -172,8 +172,8 @@ def test_cassini_k15_full_size(oracle):
     ber = int(dec.count_bit_errors(out, tx).item()) / float(frames * L)
     assert 1e-4 < ber < 0.1, ber              # ~1e-2 at 1 dB
     _oracle_subset(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L, n_pick=4, seed=3)
-    # ... and 32 whole frames per host thread through the threaded oracle (about 25 s of wall clock on the box's 16 cores:
-    # 512 of the 4096 frames), compared by digest over all 2.1 M decision words of each
+    # ... and 16 whole frames per host thread through the threaded oracle (256 of the 4096 frames on the box's 16 cores, about
+    # a minute of wall clock), compared by digest over all 2.1 M decision words of each
     n = _slabs_exact_by_digest(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L,
-                               n_slabs=16 * len(os.sched_getaffinity(0)), budget_note="K15 full size, noisy batch")
-    assert n >= 32
+                               n_slabs=8 * len(os.sched_getaffinity(0)), budget_note="K15 full size, noisy batch")
+    assert n >= 16

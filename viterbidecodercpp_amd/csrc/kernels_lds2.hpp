@@ -49,17 +49,12 @@ VIT_L2 u32 l2_add(u32 a, u32 b) { return __builtin_bit_cast(u32, (l2_u16x2)(__bu
 VIT_L2 u32 l2_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, (l2_u16x2)(__builtin_bit_cast(l2_u16x2, a) - __builtin_bit_cast(l2_u16x2, b))); }
 VIT_L2 u32 l2_min_s(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(l2_s16x2, a), __builtin_bit_cast(l2_s16x2, b))); }
 VIT_L2 u32 l2_max_s(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(l2_s16x2, a), __builtin_bit_cast(l2_s16x2, b))); }
+// plain expressions, not inline asm: the hazard recogniser pads every use of an asm statement's result with an s_nop
 VIT_L2 u32 l2_sub_sat_s(u32 a, u32 b) {
-    u32 d;
-    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+    return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(l2_s16x2, a), __builtin_bit_cast(l2_s16x2, b)));
 }
 // (a & mask) | (b & ~mask)
-VIT_L2 u32 l2_bfi(u32 mask, u32 a, u32 b) {
-    u32 d;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
-    return d;
-}
+VIT_L2 u32 l2_bfi(u32 mask, u32 a, u32 b) { return __builtin_amdgcn_bitop3_b32(a, b, mask, 0xE4); }   // truth table of mask ? a : b
 // "this wavefront's LDS reads of the block's inputs (and its table writes) are done": a RELEASE on the LDS address space in
 // front of the counter's add, so that neither the compiler nor the memory model may sink those accesses below it (a relaxed
 // add left that to the scheduler's good will).  The fence is restricted to LDS: a generic release would also wait for the

@@ -62,8 +62,11 @@ VIT_DEV u32 pk_sub(u32 a, u32 b) {
 VIT_DEV u32 pk_max_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
 }
-// (a & mask) | c in one instruction (hipcc otherwise splits the shift-in chain of the decision gather into and + or/bitop3)
-// (a & mask) | (b & ~mask)
+// (a & mask) | (b & ~mask).  Inline asm on purpose, like pk_sub_sat_s below: written as a plain expression hipcc re-associates
+// the insert tree of the decision gather into v_and + v_or3 (11 instructions instead of 7); through
+// __builtin_amdgcn_bitop3_b32 it keeps the 7, but without the asm statements as anchors the machine scheduler stretches a step
+// over 175 registers (146 with them; held to 168 it spills), which costs the two-update-waves-plus-chainback residency.  The
+// price of the asm: the hazard recogniser pads some of its uses with s_nop (2 per step at K = 7)
 VIT_DEV u32 bfi_s(u32 mask, u32 a, u32 b) {
     u32 d;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
@@ -72,7 +75,10 @@ VIT_DEV u32 bfi_s(u32 mask, u32 a, u32 b) {
 VIT_DEV u32 pk_min_s(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
 }
-// per-half SIGNED saturating subtract: the sign bit of each half is exactly (a < b) as signed 16-bit, whatever the distance
+// per-half SIGNED saturating subtract: the sign bit of each half is exactly (a < b) as signed 16-bit, whatever the distance.
+// Kept as inline asm on purpose: __builtin_elementwise_sub_sat selects the same instruction, but the sixteen asm statements of
+// a step are what keeps the machine scheduler from interleaving whole trellis steps (223 registers instead of 146 at K = 7;
+// held to 168 it spills 228 - 832 bytes per lane)
 VIT_DEV u32 pk_sub_sat_s(u32 a, u32 b) {
     u32 d;
     asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
@@ -151,6 +157,54 @@ struct RegSpec {
         if (u) x |= 1u << T;
         if (o) x |= 1u << (REG_BITS + (1 - lb));
         return pat(rotl(x, ph));
+    }
+    // ---- three-exchange lane phases (16-register codes, K = 7) ----------------------------------------------------------
+    // The two lane phases of a period are adjacent (phases 0 and 1), so the exchange that would bring the first lane bit back
+    // can instead fetch the second one: X(l1,rT) B X(l0,rT) B X(l1,rT) B serves phases 0, 1, 2 with three exchanges instead
+    // of four (8 of 32 v_permlane*_swap per period less) and leaves the two lane bits swapped; the next period runs the
+    // mirror image X(l0,rT) B X(l1,rT) B X(l0,rT) B and restores them.  The layout therefore has period 2 (K-1): lay(u, w) is
+    // the LOGICAL slot bit the physical position w (0: lane bit 5 "l1", 1: lane bit 4 "l0", 2: register bit T) holds during
+    // and after step u of a double period; register bits below T never move.  State 0 is slot 0 in every layout.
+    static constexpr bool X3 = LANE_BITS == 2 && NREG == 16;
+    static constexpr int PER = X3 ? 2 * SB : SB;              // period of the lane layout, in steps
+    static constexpr int lay(int u, int w) {
+        constexpr int HI = SB - 1, MID = SB - 2;
+        const int v = ((u % PER) + PER) % PER;
+        const int a = v == 0 ? T : v == 1 ? T : v <= SB - 1 ? MID : v == SB ? MID : HI;               // l1
+        const int b = v == 0 ? MID : v == 1 ? HI : v <= SB - 1 ? HI : v == SB ? T : v == SB + 1 ? T : MID;   // l0
+        const int c = v == 0 ? HI : v == 1 ? MID : v <= SB - 1 ? T : v == SB ? HI : v == SB + 1 ? MID : T;   // rT
+        return w == 0 ? a : w == 1 ? b : c;
+    }
+    // the lane bit exchanged with register bit T in front of step u's butterflies: 1 = l1 (v_permlane32_swap), 0 = l0
+    // (v_permlane16_swap), -1 = none
+    static constexpr int xch(int u) {
+        const int v = ((u % PER) + PER) % PER;
+        return (v == 0 || v == 2 || v == SB + 1) ? 1 : (v == 1 || v == SB || v == SB + 2) ? 0 : -1;
+    }
+    // pattern contributed by lane group q (bit 1 = l1, bit 0 = l0) in step u of a double period
+    static constexpr u32 pat_lane3(int u, u32 q) {
+        u32 x = 0;
+        if (q & 2u) x |= 1u << lay(u, 0);
+        if (q & 1u) x |= 1u << lay(u, 1);
+        return pat(rotl(x, u % SB));
+    }
+    // logical slot held by physical position (q, r) in the layout of step u
+    static constexpr u32 slot3(int u, u32 q, u32 r) {
+        u32 x = r & ((1u << T) - 1u);
+        if ((r >> T) & 1u) x |= 1u << lay(u, 2);
+        if (q & 2u) x |= 1u << lay(u, 0);
+        if (q & 1u) x |= 1u << lay(u, 1);
+        return x;
+    }
+    // what brings the decision dword of layout step v back to the canonical slot order: 0 nothing, 1 / 2 the half-dword
+    // exchange with lane bit 5 / 4 (register bit T holds that lane bit's logical bit), 3 the swap of the two lane bits, 4 / 5 both
+    static constexpr int tail_kind(int v) {
+        if (!X3) return 0;
+        const int A = lay(v, 0), B = lay(v, 1), C = lay(v, 2);
+        const bool ex1 = A == T, ex0 = B == T;
+        const int A2 = ex1 ? C : A;                 // what l1 holds after the exchange
+        const bool lsw = A2 == SB - 2;
+        return ex1 ? (lsw ? 4 : 1) : ex0 ? (lsw ? 5 : 2) : (lsw ? 3 : 0);
     }
     // 64-bit lane mask: lanes whose group q has pattern bit i set in phase ph
     static constexpr uint64_t lane_mask(int ph, int i) {
@@ -234,7 +288,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr bool LDSBM = SP::LANE_BITS == 2;
     constexpr int GROUP = 4;
     // unrolled block: whole phases, whole decision rows, and whole 16-byte symbol chunks / whole 4-step groups
-    constexpr int U0 = clcm(clcm(SB, GROUP), SPS);
+    constexpr bool X3 = SP::X3;          // three-exchange lane phases: the lane layout has period PER = 2 (K-1)
+    constexpr int PER = SP::PER;
+    constexpr int U0 = clcm(clcm(PER, GROUP), SPS);
     // LDS ring, in steps: the slot of step t is t % RING, a compile-time constant because RING divides the block length; 16 KiB
     // per wave at most, so that eight waves still fit a CU (R = 4 with 6 state bits: 8 steps, block of 24)
     constexpr int RING = !LDSBM ? 1 : (U0 * NP * 128 <= 16384 ? U0 : 8);
@@ -246,7 +302,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : (U / GROUP) % 2 == 0 ? 2 : (U / GROUP) % 7 == 0 ? 7 : 1);
     constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
     static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
-    constexpr bool RDTAB = SB * NP <= 32;         // read indices per (phase, pattern) in registers; else per phase + one v_xor per read
+    constexpr bool RDTAB = SB * NP <= 32;         // read indices per (layout step, pattern) in registers; else per step + one v_xor per read
     constexpr int ROW = NP * 16;                  // uint2 {E, EB} entries per step: [pattern][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
@@ -285,10 +341,19 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // new_metric[0] >= threshold  <=>  biased metric > biased (threshold - 1); threshold == 0 means "always"
     const u32 THRM1B2 = ((u32)(uint16_t)(a.cfg.threshold - 1) * 0x10001u) ^ BIAS2;
     const u32 FORCE = a.cfg.threshold == 0 ? BIAS2 : 0u;
-    const u32 MASKQ = q == 0 ? BIAS2 : 0u;   // state 0 is slot 0: lane group q == 0, register 0
+    // state 0 is slot 0: lane group q == 0, register 0
+    // the per-step test "does any frame of this wave renormalise" in two instructions: max(m[0], TLANE) != TLANE  <=>  some
+    // half of m[0] exceeds the threshold; lanes that do not hold state 0 compare against the largest value (never exceeded).
+    // Threshold 0 ("always"): the maximum is pinned to the largest value and compared with a constant it can never equal.
+    // The sign bits the rare branch needs are formed inside it.
+    const u32 TLANE = (q == 0 && a.cfg.threshold != 0) ? THRM1B2 : 0x7FFF7FFFu;
+    const u32 TCMP = (q == 0 && a.cfg.threshold == 0) ? 0u : TLANE;
     // v_perm selectors {own = bytes 4-7, partner = bytes 0-3} for the half-dword exchange after a lane-bit phase
     const u32 SELX32 = (lane & 32) ? 0x07060302u : 0x01000504u;
     const u32 SELX16 = (lane & 16) ? 0x07060302u : 0x01000504u;
+    // ds_bpermute addresses: the lane with the two lane-group bits swapped (q = 1 <-> q = 2), and the exchange partners
+    const u32 LSWADDR = 4u * (u32)((lane & 15) | ((lane & 16) << 1) | ((lane & 32) >> 1));
+    const u32 XADDR32 = 4u * (u32)(lane ^ 32), XADDR16 = 4u * (u32)(lane ^ 16);
 
     // the branch pattern contributed by this lane's group q is folded in by exchanging `high` and `low` per polynomial:
     // per-lane constants, one pair per (phase, polynomial)
@@ -307,12 +372,14 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     }
     // LDSBM: ring index (uint2 units) this lane READS pattern p from in phase ph: entry (p ^ pat_lane(ph, q)) of pair g;
     // and the one it WRITES its own step of a group to (step 4J+q: row q of the group, pattern 0, pair g)
-    u32 rd_idx[LDSBM && RDTAB ? SB : 1][NP], rd_x[LDSBM && !RDTAB ? SB : 1];
+    u32 rd_idx[LDSBM && RDTAB ? PER : 1][NP], rd_x[LDSBM && !RDTAB ? PER : 1];
     const u32 wr_idx = q * ROW + g;
     if constexpr (LDSBM) {
-        static_for<SB>([&](auto pc) __attribute__((always_inline)) {
+        static_for<PER>([&](auto pc) __attribute__((always_inline)) {
             constexpr int ph = decltype(pc)::value;
-            const u32 x = q == 0 ? SP::pat_lane(ph, 0) : q == 1 ? SP::pat_lane(ph, 1) : q == 2 ? SP::pat_lane(ph, 2) : SP::pat_lane(ph, 3);
+            u32 x;
+            if constexpr (X3) x = q == 0 ? SP::pat_lane3(ph, 0) : q == 1 ? SP::pat_lane3(ph, 1) : q == 2 ? SP::pat_lane3(ph, 2) : SP::pat_lane3(ph, 3);
+            else x = q == 0 ? SP::pat_lane(ph, 0) : q == 1 ? SP::pat_lane(ph, 1) : q == 2 ? SP::pat_lane(ph, 2) : SP::pat_lane(ph, 3);
             if constexpr (RDTAB) {
                 static_for<NP>([&](auto ppc) __attribute__((always_inline)) {
                     constexpr u32 p = decltype(ppc)::value;
@@ -332,10 +399,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     u32 m[NREG];
     if (RESUME) {
         const int ph = (int)(T_BEGIN % SB);
+        const int lu = (int)((T_BEGIN + (u32)PER - 1u) % (u32)PER);   // the layout step T_BEGIN - 1 left behind (canonical before step 0)
         constexpr size_t N = (size_t)1 << SB;
         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
             constexpr u32 r = decltype(rc)::value;
-            const u32 x = (q << REG_BITS) | r;
+            const u32 x = X3 ? SP::slot3(lu, q, r) : ((q << REG_BITS) | r);
             const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;
             u32 lo, hi;
             if (SHIFT) {
@@ -391,6 +459,8 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
 
     uint64_t rsA = 0, rsB = 0;
     u32 dq[4] = {0, 0, 0, 0};
+    u32 pend_acc = 0, pend_f1 = 0, pend_f2 = 0;   // three-exchange layouts: a step's decision dword and its cross-lane fetches, consumed one step later
+    static_assert(!X3 || SP::tail_kind((U - 1) % PER) == 0, "the last step of an unrolled block leaves no decision fetch pending");
     uint4* ws_tile = a.ws + tile * a.ws_tile_stride;
 
     // E[p] = sum_i |bt_i - y_i| for every branch pattern p and EB[p] = max_error - E[p]  (scalar.h:66-73,107) of block
@@ -468,7 +538,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // LDSBM consumer: this lane's view of block step `un` (un == U: step 0 of the next block)
     auto bm_fetch = [&](auto unc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value;
-        constexpr int us = un % U, PHn = us % SB, buf = un & 1;
+        constexpr int us = un % U, PHn = us % PER, buf = un & 1;
         static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
             u32 idx;
@@ -534,9 +604,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 // a resumed call enters its first block in the middle: the steps below t_begin only keep the look-ahead
                 // pipeline above running
                 if (!GUARDED || !RESUME || t0 + u >= T_BEGIN) {
-                constexpr bool LP = SP::lane_phase(PH);
-                constexpr int PB = LP ? T : SP::pbit(PH);          // register bit the butterflies pair on
-                constexpr int LB = LP ? SP::pbit(PH) - REG_BITS : 0;
+                constexpr int UP = u % PER;                        // step of the lane layout's (double) period
+                constexpr bool LP = !X3 && SP::lane_phase(PH);     // classic scheme: exchange, butterflies, exchange back
+                constexpr int XCH = X3 ? SP::xch(UP) : -1;         // three-exchange scheme: ONE exchange in front of the butterflies
+                constexpr int PB = (LP || (X3 && PH < SB - REG_BITS + 1)) ? T : SP::pbit(PH);   // register bit the butterflies pair on
+                constexpr int LB = LP ? SP::pbit(PH) - REG_BITS : (XCH >= 0 ? XCH : 0);
                 auto lane_swap = [&](u32& x0, u32& x1) __attribute__((always_inline)) {
                     if constexpr (LB == 1) {
                         auto r2 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
@@ -546,7 +618,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         x0 = r2[0]; x1 = r2[1];
                     }
                 };
-                if constexpr (LP) {
+                if constexpr (LP || XCH >= 0) {
                     static_for<NREG / 2>([&](auto hc) __attribute__((always_inline)) {
                         constexpr int r0 = decltype(hc)::value;   // bit T clear because r0 < NREG/2
                         lane_swap(m[r0], m[r0 | (1 << T)]);
@@ -610,16 +682,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         }
                     }
                 });
-                // ---- renormalisation test early (needs only the new metric of state 0 = slot 0) ----
-                const u32 need = (pk_sub_sat_s_uniform(THRM1B2, LP ? 0u : m[0]) | FORCE) & MASKQ;   // sign bits: frame A / frame B
                 if constexpr (!CHUNKED) static_for<DW>([&](auto dc) __attribute__((always_inline)) { gather(dc); });
-                if constexpr (LP && NREG == 16) {
-                    // registers 0-7 / 8-15 (low / high half of the dword) belong to different lanes until the exchange is
-                    // undone: lane bit 0 keeps its low half and takes the partner's low half as its high half; lane bit 1
-                    // takes the partner's high half as its low half and keeps its high half
-                    const u32 partner = (u32)__shfl_xor((int)acc[0], LB == 1 ? 32 : 16);
-                    acc[0] = __builtin_amdgcn_perm(acc[0], partner, LB == 1 ? SELX32 : SELX16);
-                }
                 if constexpr (LP && NREG > 16) {
                     static_for<DW / 2>([&](auto dc) __attribute__((always_inline)) {
                         constexpr int d = decltype(dc)::value;
@@ -635,18 +698,69 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 // ---- decision rows: 16 bytes per lane, 1 KiB per wave, coalesced ----
                 if constexpr (DW == 4) {
                     ws_blk[u * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                } else {
+                } else if constexpr (!X3) {
                     static_for<DW>([&](auto dc) __attribute__((always_inline)) {
                         constexpr int d = decltype(dc)::value;
                         dq[(u % SPS) * DW + d] = acc[d];
                     });
                     if constexpr (u % SPS == SPS - 1)
                         ws_blk[(u / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                } else {
+                    // Three-exchange layouts: the decision dword goes back to the canonical slot order (rows stay what chainback
+                    // and export read) through cross-lane fetches -- the half-dword exchange with the lane whose register bit T
+                    // holds one of this lane's logical bits (EX: one ds_bpermute + v_perm: lane bit 0 keeps its low half and
+                    // takes the partner's low half as its high half, lane bit 1 takes the partner's high half as its low half and
+                    // keeps its high half), the lane permutation that swaps the two lane bits (LSW: one ds_bpermute), or both
+                    // (two independent ds_bpermute + v_perm).  A ds_bpermute takes a hundred cycles and more to come back and a
+                    // wave waits for it in order (s_waitcnt lgkmcnt): the fetches of step u are therefore CONSUMED in step u + 1,
+                    // behind that step's add-compare-select (unguarded blocks; the last step of a block needs none, so nothing is
+                    // pending across blocks).
+                    auto finish_tail = [&](auto vc) __attribute__((always_inline)) {
+                        constexpr int v = decltype(vc)::value;
+                        constexpr int KV = SP::tail_kind(v % PER);
+                        u32 fin;
+                        if constexpr (KV == 1) fin = __builtin_amdgcn_perm(pend_acc, pend_f1, SELX32);
+                        else if constexpr (KV == 2) fin = __builtin_amdgcn_perm(pend_acc, pend_f1, SELX16);
+                        else if constexpr (KV == 3) fin = pend_f1;
+                        else if constexpr (KV == 4) fin = __builtin_amdgcn_perm(pend_f1, pend_f2, SELX16);   // EX1 seen from lane LSW(l): its bit 5 is my bit 4
+                        else fin = __builtin_amdgcn_perm(pend_f1, pend_f2, SELX32);
+                        dq[v % SPS] = fin;
+                        if constexpr (v % SPS == SPS - 1)
+                            ws_blk[(v / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                    };
+                    constexpr int KU = SP::tail_kind(UP);
+                    constexpr bool DEFER = !GUARDED;
+                    if constexpr (DEFER && u > 0) {
+                        if constexpr (SP::tail_kind((u - 1) % PER) != 0) finish_tail(std::integral_constant<int, u - 1>{});
+                    }
+                    if constexpr (KU == 0) {
+                        dq[u % SPS] = acc[0];
+                        if constexpr (u % SPS == SPS - 1)
+                            ws_blk[(u / SPS) * 64 + lane] = make_uint4(dq[0], dq[1], dq[2], dq[3]);
+                    } else {
+                        pend_acc = acc[0];
+                        if constexpr (KU == 1) pend_f1 = (u32)__builtin_amdgcn_ds_bpermute((int)XADDR32, (int)acc[0]);
+                        else if constexpr (KU == 2) pend_f1 = (u32)__builtin_amdgcn_ds_bpermute((int)XADDR16, (int)acc[0]);
+                        else pend_f1 = (u32)__builtin_amdgcn_ds_bpermute((int)LSWADDR, (int)acc[0]);
+                        if constexpr (KU == 4) pend_f2 = (u32)__builtin_amdgcn_ds_bpermute((int)(LSWADDR ^ 128u), (int)acc[0]);
+                        if constexpr (KU == 5) pend_f2 = (u32)__builtin_amdgcn_ds_bpermute((int)(LSWADDR ^ 64u), (int)acc[0]);
+                        if constexpr (!DEFER) finish_tail(uc);
+                    }
                 }
-                // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153); state 0 is slot 0 ----
+                // ---- renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153); state 0 is slot 0 (of lane group
+                //      0, register 0) in every layout ----
                 {
-                    const u32 need2 = LP ? ((pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & MASKQ) : need;
-                    if (__builtin_amdgcn_ballot_w64(need2 != 0) != 0) {
+                    bool any;
+                    if constexpr (NREG >= 64) {
+                        // 64-register codes (K = 9) have no register to spare for a second per-lane constant: three instructions of 356
+                        const u32 maskq0 = lane < 16 ? BIAS2 : 0u;
+                        any = __builtin_amdgcn_ballot_w64(((pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq0) != 0) != 0;
+                    } else {
+                        any = __builtin_amdgcn_ballot_w64(pk_max_s(m[0], TLANE) != TCMP) != 0;
+                    }
+                    if (any) {
+                        const u32 maskq = (SP::LANE_BITS == 0 || lane < 16) ? BIAS2 : 0u;              // formed here, not carried through the hot path
+                        const u32 need2 = (pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq;   // sign bits: frame A / frame B
                         const u32 nq = SP::LANE_BITS ? (u32)__shfl((int)need2, (int)g) : need2;
                         const u32 msk = ((nq & 0x8000u) ? 0x0000FFFFu : 0u) | ((nq & 0x80000000u) ? 0xFFFF0000u : 0u);
                         u32 mn = m[0];
@@ -689,10 +803,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // ---- final metrics in state order (get_error / m_metrics "old" buffer) ----
     if (a.metrics_out) {
         const int ph = (int)(a.t_end % SB);
+        const int lu = (int)((a.t_end + (u32)PER - 1u) % (u32)PER);      // the lane layout step t_end - 1 left behind
         constexpr size_t N = (size_t)1 << SB;
         static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
             constexpr u32 r = decltype(rc)::value;
-            const u32 x = (q << REG_BITS) | r;
+            const u32 x = X3 ? SP::slot3(lu, q, r) : ((q << REG_BITS) | r);
             const u32 s = ((x << ph) | (x >> (SB - ph))) & SP::SMASK;   // state held by slot x after step t_end - 1
             const u32 v = m[r] ^ BIAS2;
             if (SHIFT) {
