@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Instruction mix of the fast block of lds2_update_kernel<15,0> in a hipcc -S dump of vit_hip.hip: the code between two
-s_barrier that holds the 64 table reads and the eight 16-byte metric stores.  usage: k15_block_stats.py build/vit_hip.s [K]"""
+s_barrier that holds the 64 table reads and the eight 16-byte metric stores.  usage: k15_block_stats.py build/vit_hip.s [K [RT]]"""
 import re, sys
 from collections import Counter
 s = open(sys.argv[1]).read()
 K = sys.argv[2] if len(sys.argv) > 2 else "15"
-m = re.search(r'^(_ZN3vit18lds2_update_kernelILi' + K + r'ELi0EEEvNS_14Lds2UpdateArgsE):', s, re.M)
+RT = sys.argv[3] if len(sys.argv) > 3 else ("6" if K == "15" else "0")
+m = re.search(r'^(_ZN3vit18lds2_update_kernelILi' + K + r'ELi0ELi' + RT + r'EEEvNS_14Lds2UpdateArgsE):', s, re.M)
 body = s[m.end():s.index('.Lfunc_end', m.end())]
 segs, seg = [], []
 for l in body.split('\n') + ['s_barrier']:

@@ -63,6 +63,15 @@ VIT_L2 void lds2_arrive(u32* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// e += d on the lanes of `lanes` only, d wave-uniform: the packed add runs under a temporary exec mask (scalar moves around one
+// VALU instruction; the caller's exec mask is all ones or the code is not reached)
+VIT_L2 u32 l2_add_where(u32 e, u32 d_uniform, uint64_t lanes) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_pk_add_u16 %0, %0, %2\n\ts_mov_b64 exec, %1"
+                 : "+v"(e), "=&s"(save)
+                 : "s"(d_uniform), "s"(lanes));
+    return e;
+}
 VIT_L2 void l2_opaque(u32& x) { asm volatile("" : "+v"(x)); }   // the compiler may not assume anything about x across this point
 template <class F, int... Is>
 VIT_L2 void l2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -157,7 +166,9 @@ struct Lds2Geom {
 // the first three steps) is therefore PREDICTED, not discovered -- new[0] <= old[0] + E[pattern 0], so thread 0 bounds
 // metric[0] over the next block's first three steps from that block's (already built) tables and, if the bound reaches the
 // threshold, the whole workgroup takes the careful stage-by-stage routine for that block.
-template <int K, int SHIFT>
+// RT: the code rate as a compile-time constant (the Cassini instantiation: the six per-symbol loops lose their run-time bound
+// checks and the phi copies around them), or 0 = taken from the arguments (any R <= 6).
+template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update_kernel(Lds2UpdateArgs a) {
     using GM = Lds2Geom<K>;
     constexpr int N = GM::N, T = GM::T, G = GM::G, GPT = GM::GPT, NW = GM::NW, BLK = GM::BLK, SBITS = GM::SBITS;
@@ -173,7 +184,10 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     uint64_t* const rs_acc = (uint64_t*)(flag + 8);            // [2] sum of subtracted minima, frame A / B (thread 0 only)
     u32* const met = flag + 16;                                // [N], 16-byte aligned
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wavefront's index, pinned uniform: everything derived from it (which table it builds, whether it builds one at all)
+    // is then scalar control flow and scalar data, not exec-mask branches over vector compares
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the step range, pinned uniform up front: read where it is needed, the compiler re-loads it on one side of a per-thread
     // branch (tid == 0 ...) and merges the copies in a phi that counts as divergent -- and with it the block loop's counter,
     // its table-set bit and every branch on them (vector compares, exec-mask branches, loop counters in VGPRs)
@@ -182,7 +196,7 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     const u32 fA = 2 * pair;
     const bool validB = fA + 1 < a.frames;
     const u32 fB = validB ? fA + 1 : fA;
-    const int R = a.R;
+    const int R = RT ? RT : a.R;
 
     const u32 HIGH2 = (u32)(uint16_t)a.cfg.high * 0x10001u, LOW2 = (u32)(uint16_t)a.cfg.low * 0x10001u;
     const u32 MAXE2 = (u32)a.cfg.max_error * 0x10001u;
@@ -263,23 +277,69 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 #pragma unroll
         for (int c = 0; c < BLK; ++c) xorB[c] = (u32)a.pattern[(size_t)1 << (GM::JB - 1 + c)] & 63u;
     }
+#ifndef VIT_L2_SCALAR_BUILD
+    // lane p: E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107),
+    // stored at position lds2_tab_index(p): 70 VALU per table pair, on four of the eight wavefronts
     auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
-        // lane p: E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107),
-        // stored at position lds2_tab_index(p)
         u32 e = 0, eb = 0;
         const u32 pb = (u32)lane ^ xb;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
                 const u32 d1 = l2_sub(HIGH2, y[i]), d0 = l2_sub(LOW2, y[i]);
-                const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));   // error_t(get_abs(soft_t(expected - sym)))  (scalar.h:68-71)
+                const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
                 e = l2_add(e, ((lane >> i) & 1) ? a1 : a0);
                 eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
             }
         }
         tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
+        if constexpr (GPT == 2) tab[64 + pos] = make_uint2(eb, l2_sub(MAXE2, eb));
+    };
+#else
+    // EXPERIMENT, measured SLOWER (K15 4096 x 8192: 50.8 ms against 49.5): everything that does not depend on the lane on the
+    // scalar unit, one exec-masked packed add per symbol -- 14 VALU per table pair instead of 70, but 250 dependent scalar
+    // instructions in front of the building wavefronts' add-compare-select: they reach the block's barrier late and the other
+    // four wait for them.
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
+        // The symbols are wave-uniform, so everything that does not depend on p runs on
+        // the SCALAR unit (idle in this VALU-bound kernel): per symbol a0 = |low - y|, a1 = |high - y| for both frames, the
+        // base sum S0 = sum a0 and the deltas d_i = a1 - a0.  E[p] = S0 + sum over the set bits of p of d_i is then ONE packed add
+        // per symbol under an exec mask that holds the lanes with bit i set (v_pk_add_u16 with the delta straight from an
+        // SGPR): 14 VALU per table pair, where per-lane selects took 70.
+        const int hi16 = (int)a.cfg.high, lo16 = (int)a.cfg.low;
+        auto absd = [](int expected, u32 sym16) __attribute__((always_inline)) -> u32 {
+            const int d = (int)(int16_t)(uint16_t)((u32)expected - sym16);          // soft_t(expected - sym), wrapping
+            return (u32)(d < 0 ? -d : d) & 0xFFFFu;                                 // error_t(get_abs(...)): |-32768| stays 0x8000
+        };
+        u32 sAl = 0, sAh = 0, sBl = 0, sBh = 0, dA[6], dB[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dA[i] = 0; dB[i] = 0;
+            if (i < R) {
+                const u32 yl = y[i] & 0xFFFFu, yh = y[i] >> 16;
+                const u32 a1l = absd(hi16, yl), a0l = absd(lo16, yl), a1h = absd(hi16, yh), a0h = absd(lo16, yh);
+                const bool flip = (xb >> i) & 1u;            // table B holds E[p ^ xb]: where xb has bit i, a0 and a1 change places
+                sAl += a0l; sAh += a0h;
+                sBl += flip ? a1l : a0l; sBh += flip ? a1h : a0h;
+                const u32 dl = (a1l - a0l) & 0xFFFFu, dh = (a1h - a0h) & 0xFFFFu;
+                dA[i] = dl | (dh << 16);
+                dB[i] = flip ? (((0u - dl) & 0xFFFFu) | ((0u - dh) << 16)) : dA[i];
+            }
+        }
+        u32 e = (sAl & 0xFFFFu) | (sAh << 16), eb = (sBl & 0xFFFFu) | (sBh << 16);
+        constexpr uint64_t LANES[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
+                                       0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < R) {
+                e = l2_add_where(e, dA[i], LANES[i]);
+                if constexpr (GPT == 2) eb = l2_add_where(eb, dB[i], LANES[i]);
+            }
+        }
+        tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
         if constexpr (GPT == 2) tab[64 + pos] = make_uint2(eb, l2_sub(MAXE2, eb));   // the group-B table holds E[p ^ xb] where A holds E[p]
     };
+#endif
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
     constexpr int CPW = GM::CPW;
     // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
@@ -300,8 +360,13 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
-            const int c = wave + NW * i;
-            if (c < BLK && t0 + (u32)c < t_end && t0 + (u32)c >= t_begin) load_syms(t0 + (u32)c, yland[i]);
+            // unconditional, from a step clamped into the chunk [t_begin, t_end): a load under a condition makes the landing
+            // registers a phi of old and new values (six register copies on every path around it); what a clamped step
+            // fetches is never used (tables_build skips the steps outside the range)
+            u32 ts = t0 + (u32)((wave + NW * i) & (BLK - 1));
+            ts = ts < t_begin ? t_begin : ts;
+            ts = ts >= t_end ? t_end - 1u : ts;
+            load_syms(ts, yland[i]);
         }
     };
     auto tables_commit = [&]() __attribute__((always_inline)) {
@@ -386,51 +451,69 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     // the unpacked values cannot be hoisted out of the block loop -- hoisted, they were 32 loop-invariant registers that
     // the 128-register budget does not have (hipcc spilled 9-22 of them, and every reload's s_waitcnt vmcnt also waited for
     // the decision stores in flight)
+    u32 tab_set_base = 0;                       // byte offset of the table set the current block reads (0 or SET_TAB)
     auto stage_all = [&](auto cc, u32* wsp) __attribute__((always_inline)) {   // wsp: decision row of block step 0
         constexpr int C = decltype(cc)::value;
         u32 addr[8];
         l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value;
-            addr[h] = (h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu);
+            addr[h] = tab_set_base + ((h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu));
         });
-        stage(cc, mA, addr, 0u, wsp + C * G + tid);
-        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, wsp + C * G + T + tid);
+        // the row of this stage: a scalar base per stage (its offset pinned uniform, so that it is not derived from the previous
+        // stage's per-thread address with a 64-bit vector add: rows are 4 KiB apart, beyond the store's immediate offset)
+        u32 row_off = (u32)(C * G);
+        asm volatile("" : "+s"(row_off));          // an SGPR whose value the compiler does not know
+        u32* const row = wsp + row_off;
+        stage(cc, mA, addr, 0u, row + tid);
+        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + tid);
         __builtin_amdgcn_sched_barrier(0);
     };
     // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
     constexpr bool SEP = (G / 16) % 8 == 0;     // r*G/16 does not reach the three bits the swizzle touches: base + r*G/4
-    // Addresses are formed from an OPAQUE copy of the thread index inside every block: left to itself hipcc hoists the 32 + 8
-    // per-register addresses out of the main loop and spills them (236 bytes of scratch, ~50 reloads per block); this way a
-    // group's reads are one base register + instruction offsets and the four store addresses cost one v_xor each.
-    auto load_group = [&](u32 (&m)[16], u32 g) __attribute__((always_inline)) {
-        const u32* const p = met + lds2_sw(g, (u32)N);
+    // Addresses: ONE byte offset per thread for the 16 / 32 metric reads of a block (register r of group A at +r*G bytes, group
+    // B another T bytes up: instruction offsets) and FOUR for its stores (piece q of group A; group B 16 T bytes up), all
+    // relative to lds2_smem and formed once, in front of the block loop.  Each use goes through an OPAQUE copy (an empty asm: no
+    // instruction): left to itself hipcc materialises the 32 + 8 derived addresses as loop-invariant registers and spills them
+    // (236 bytes of scratch, ~50 reloads per block); re-forming them from the thread index in every block, as round 2 did,
+    // cost 27 VALU per block.
+    constexpr u32 MET_OFF = (u32)GM::tab_bytes + 32u * 4u;                 // byte offset of met[] inside lds2_smem
+    const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)tid, (u32)N);
+    // the compile-time-rate instantiation has the registers for all four store offsets; the others carry one and form the rest
+    // with a v_xor each
+    constexpr int NST = RT ? 4 : 1;
+    u32 st_off[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)tid ^ (u32)(q << 1));
+    auto at = [&](u32 byte_off) __attribute__((always_inline)) -> char* { return (char*)lds2_smem + byte_off; };
+    auto load_group = [&](u32 (&m)[16], u32 g, u32 off) __attribute__((always_inline)) {
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            if constexpr (SEP) m[r] = p[r * (G / 4)];
+            if constexpr (SEP) m[r] = *(const u32*)at(off + (u32)(r * (G / 4)) * 4u);
             else m[r] = met[lds2_sw((u32)(r * G) + g, (u32)N)];
         });
     };
-    auto store_group = [&](const u32 (&m)[16], u32 g) __attribute__((always_inline)) {   // after stage 3: register r holds state 16 g + r
+    auto load_metrics = [&]() __attribute__((always_inline)) {
+        u32 o = ld_off, t = (u32)tid;
+        l2_opaque(o);
+        l2_opaque(t);
+        load_group(mA, t, o);
+        if constexpr (GPT == 2) load_group(mB, t + (u32)T, o + (u32)T);      // lds2_sw(g + T) = lds2_sw(g) + T / 4 dwords
+    };
+    auto store_metrics = [&]() __attribute__((always_inline)) {                 // after stage 3: register r holds state 16 g + r
         l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
-            uint4* const p = (uint4*)(met + q * (N / 4)) + (g ^ (u32)(q << 1));
-            *p = make_uint4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+            u32 o;
+            if constexpr (NST == 4) {
+                o = st_off[q];
+                l2_opaque(o);
+            } else {
+                u32 o0 = st_off[0];
+                l2_opaque(o0);
+                o = ((o0 - MET_OFF) ^ (u32)(q << 5)) + MET_OFF + 4u * (u32)(q * (N / 4));   // 16 (tid ^ 2q) = 16 tid ^ 32 q
+            }
+            *(uint4*)at(o) = make_uint4(mA[4 * q], mA[4 * q + 1], mA[4 * q + 2], mA[4 * q + 3]);
+            if constexpr (GPT == 2) *(uint4*)at(o + 16u * (u32)T) = make_uint4(mB[4 * q], mB[4 * q + 1], mB[4 * q + 2], mB[4 * q + 3]);
         });
-    };
-    auto opaque_tid = [&]() __attribute__((always_inline)) -> u32 {
-        u32 t = (u32)tid;
-        asm volatile("" : "+v"(t));
-        return t;
-    };
-    auto load_metrics = [&]() __attribute__((always_inline)) {
-        const u32 t = opaque_tid();
-        load_group(mA, t);
-        if constexpr (GPT == 2) load_group(mB, t + (u32)T);
-    };
-    auto store_metrics = [&]() __attribute__((always_inline)) {
-        const u32 t = opaque_tid();
-        store_group(mA, t);
-        if constexpr (GPT == 2) store_group(mB, t + (u32)T);
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
     auto renormalise = [&](u32 need) __attribute__((always_inline)) {
@@ -552,11 +635,13 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
         const int c_first = t0 < t_begin ? (int)(t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
         if (nst < BLK || c_first > 0 || careful != 0) careful = slow_block(t0, set, c_first, nst);
         else careful = fast_block(set, t0, arrivals_wanted);
-        // the next block reads the other table set: flip the set bit in all packed offsets
+        // the next block reads the other table set: one base offset flips; the packed offsets are made opaque once per block (no
+        // instruction), so that their unpacked values cannot be hoisted out of the loop as 32 loop-invariant registers
+        tab_set_base ^= SET_TAB;
 #pragma unroll
         for (int c = 0; c < BLK; ++c)
 #pragma unroll
-            for (int h2 = 0; h2 < 4; ++h2) prow2[c][h2] ^= SET_TAB * 0x10001u;
+            for (int h2 = 0; h2 < 4; ++h2) l2_opaque(prow2[c][h2]);
         arrivals_wanted += (u32)NW;
         t0 += (u32)BLK;
         set ^= 1;
@@ -684,7 +769,7 @@ inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
 template <int K, int SHIFT>
 int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) {
     using GM = Lds2Geom<K>;
-    auto kern = lds2_update_kernel<K, SHIFT>;
+    auto kern = (K == 15 && a.R == 6) ? lds2_update_kernel<K, SHIFT, (K == 15 ? 6 : 0)> : lds2_update_kernel<K, SHIFT, 0>;
     if (GM::smem_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)GM::smem_bytes) != hipSuccess)
