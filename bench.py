@@ -28,10 +28,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4
-# cycles one SIMD needs per wave64 VALU instruction in a stream of packed 16-bit / VOP3 forms at >= 2 waves per SIMD, measured
-# on the box with scripts/ubench/valu_rate.hip (profiles/r1_valu_issue_rates.txt)
-VALU_CYCLES_PER_INSTR = 4.3
+CLOCK_GHZ = 2.4          # peak engine clock (the measured clock under load is read by vit_hip_shader_clock_mhz in every run)
+
+
+def issue_rates():
+    """measured issue cost of the update kernels' instruction class (packed 16-bit / VOP3), in ns per wave64 instruction per
+    SIMD by waves per SIMD: profiles/issue_rates.json, written from profiles/r3_valu_issue_rates.txt (wall-clock timed on the
+    card: no clock assumption)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "issue_rates.json")))
+    except (OSError, ValueError):
+        return None
 
 
 # BASELINE.json configs[i] -> (index into COMMON_CODES, decode type, frames per GPU, info bits per frame, Eb/N0 dB)
@@ -510,24 +517,28 @@ def main():
         "state_updates_per_s": state_updates / (upd_ms * 1e-3),
         "ber": ber,
     }
-    if valu_insts:
-        peak_ginstr = N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INSTR       # wave64 VALU instructions per ns over the chip
-        ach = valu_insts / (upd_ms * 1e-3) / 1e9
-        result["roofline_valu"] = {
-            "bound": "valu", "kernel": "update", "achieved": ach, "peak": peak_ginstr, "unit": "G wave-instr/s",
-            "frac": ach / peak_ginstr, "valu_insts_per_launch": valu_insts,
-            "valu_insts_per_state_update_pair": valu_insts * 64.0 / (state_updates / 2.0),
-            "peak_source": f"{N_SIMD} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES_PER_INSTR} cycles per packed-16 VALU instruction "
-                           "(profiles/r1_valu_issue_rates.txt)",
-            "insts_source": traffic_src}
-        # the hardware's own issue rate depends on how many waves share a SIMD (profiles/r2_dep_rate.txt: an independent
-        # stream of v_pk_add_u16 issues at 5.27 / 4.52 / 4.40 / 4.29 cycles with 1 / 2 / 3 / 4 waves): the batch decides that
-        dec._handle.refresh()
+    rates = issue_rates()
+    if valu_insts and rates:
+        # Two ceilings for the update kernel's vector-instruction rate.  "measured": what a pure stream of packed 16-bit
+        # instructions issues at, timed on the card by wall clock (no clock assumed), with as many waves per SIMD as this batch
+        # gives the update kernel.  "spec": 2 clocks per wave64 instruction at the 2.4 GHz peak clock (the guide's VOP2-class
+        # rate; packed 16-bit forms do not reach it: 4.3 - 4.5 clocks measured).
+        ns = rates["packed16_ns_per_wave_instr_per_simd"]
+        waves = None
         if dec.plan == _lib.PLAN_REG:
-            waves = -(-F // dec._handle.info.workspace_tile_frames) / float(N_SIMD)
-            cyc = 5.27 if waves <= 1 else 4.52 if waves <= 2 else 4.40 if waves <= 3 else 4.29
-            result["roofline_valu"]["update_waves_per_simd"] = waves
-            result["roofline_valu"]["frac_of_issue_rate_at_that_occupancy"] = ach / (N_SIMD * CLOCK_GHZ / cyc)
+            waves = -(-F // tile_frames) / float(N_SIMD) * NUPD
+        wkey = "4" if waves is None else str(int(min(4, max(1, -(-waves // 1)))))
+        peak_measured = N_SIMD / ns[wkey]                                  # G wave-instructions per second over the chip
+        peak_spec = N_SIMD * rates["spec_clock_ghz"] / rates["spec_cycles_per_wave64_instr"]
+        ach = valu_insts / (upd_ms * 1e-3) / 1e9 * NUPD                    # NUPD launches share the SIMDs while each one runs
+        result["roofline_valu"] = {
+            "bound": "valu", "kernel": "update", "achieved": ach, "peak": peak_measured, "unit": "G wave-instr/s",
+            "frac": ach / peak_measured, "peak_spec": peak_spec, "frac_of_spec": ach / peak_spec,
+            "valu_insts_per_launch": valu_insts, "launches_in_flight": NUPD,
+            "valu_insts_per_state_update_pair": valu_insts * 64.0 / (state_updates / 2.0),
+            "update_waves_per_simd": waves, "ns_per_packed_instr_per_simd_at_that_occupancy": ns[wkey],
+            "shader_clock_mhz_measured_this_run": [clock_before[0], clock_after[0]],
+            "peak_source": rates["source"], "insts_source": traffic_src}
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
