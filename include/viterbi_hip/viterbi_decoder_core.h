@@ -26,6 +26,17 @@ inline void require_ok(int rc, const char* what) {
 }
 }  // namespace viterbi_hip_detail
 
+namespace viterbi_hip_detail {
+// Streamed update() calls are queued on the host and run on the GPU in one launch (ViterbiDecoder_Core::flush_pending).
+// The public data members callers may read directly -- m_metrics.get_old(), m_decisions[row] -- bring the decoder up to
+// date first through this hook (a null hook: nothing is ever pending).
+struct FlushHook {
+    void (*fn)(void*) = nullptr;
+    void* owner = nullptr;
+    void operator()() const { if (fn) fn(owner); }
+};
+}  // namespace viterbi_hip_detail
+
 // double-buffered path metrics; after every update() the "old" buffer holds the live metrics
 template <size_t constraint_length, typename error_t>
 class ViterbiErrorMetrics {
@@ -33,12 +44,15 @@ public:
     static constexpr size_t K = constraint_length;
     static constexpr size_t TOTAL_STATE_BITS = K - 1;
     static constexpr size_t NUMSTATES = size_t(1) << TOTAL_STATE_BITS;
-    error_t* get_old() { return m_buf[m_index]; }
-    error_t* get_new() { return m_buf[1 - m_index]; }
+    error_t* get_old() { m_hook(); return m_buf[m_index]; }
+    error_t* get_new() { m_hook(); return m_buf[1 - m_index]; }
     void swap() { m_index = 1 - m_index; }
+    error_t* raw_old() { return m_buf[m_index]; }                       // no flush: the decoder's own accesses
+    void set_flush_hook(viterbi_hip_detail::FlushHook h) { m_hook = h; }
 private:
     alignas(64) error_t m_buf[2][NUMSTATES];
     size_t m_index = 0;
+    viterbi_hip_detail::FlushHook m_hook;
 };
 
 // decision history: row t = max(NUMSTATES/64, 1) 64-bit words, bit s%64 of word s/64 = decision for next-state s
@@ -50,13 +64,16 @@ public:
     static constexpr size_t NUMSTATES = size_t(1) << (K - 1);
     static constexpr size_t TOTAL_BITS_PER_BLOCK = sizeof(format_t) * 8;
     static constexpr size_t TOTAL_BLOCKS = (NUMSTATES / TOTAL_BITS_PER_BLOCK) ? (NUMSTATES / TOTAL_BITS_PER_BLOCK) : 1;
-    void resize(size_t rows) { m_words.resize(rows * TOTAL_BLOCKS); m_rows = rows; }
+    void resize(size_t rows) { m_hook(); m_words.resize(rows * TOTAL_BLOCKS); m_rows = rows; }
     size_t size() const { return m_rows; }
-    format_t* operator[](size_t row) { return m_words.data() + row * TOTAL_BLOCKS; }
-    const format_t* operator[](size_t row) const { return m_words.data() + row * TOTAL_BLOCKS; }
+    format_t* operator[](size_t row) { m_hook(); return m_words.data() + row * TOTAL_BLOCKS; }
+    const format_t* operator[](size_t row) const { m_hook(); return m_words.data() + row * TOTAL_BLOCKS; }
+    format_t* raw_row(size_t row) { return m_words.data() + row * TOTAL_BLOCKS; }   // no flush: the decoder's own accesses
+    void set_flush_hook(viterbi_hip_detail::FlushHook h) { m_hook = h; }
 private:
     std::vector<format_t> m_words;
     size_t m_rows = 0;
+    viterbi_hip_detail::FlushHook m_hook;
 };
 
 template <size_t constraint_length, size_t code_rate, typename error_t, typename soft_t>
@@ -79,6 +96,9 @@ public:
             vit_hip_create(int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)), branch_table.data(), &m_config, device,
                            &m_hip),
             "vit_hip_create");
+        const viterbi_hip_detail::FlushHook hook{&ViterbiDecoder_Core::flush_hook, this};
+        m_metrics.set_flush_hook(hook);
+        m_decisions.set_flush_hook(hook);
         reset();
         set_traceback_length(0);
     }
@@ -88,6 +108,7 @@ public:
 
     // number of decoded (information) bits kept for traceback; the K-1 tail steps are added on top
     void set_traceback_length(size_t traceback_length) {
+        flush_pending();
         const size_t rows = traceback_length + TOTAL_STATE_BITS;
         m_decisions.resize(rows);
         if (m_current_decoded_bit > rows) m_current_decoded_bit = rows;
@@ -96,12 +117,15 @@ public:
 
     error_t get_error(size_t end_state = 0) {
         assert(end_state < NUMSTATES);
-        return m_metrics.get_old()[end_state];
+        return m_metrics.get_old()[end_state];      // get_old() runs whatever update() calls are still queued
     }
 
     void reset(size_t starting_state = 0) {
+        m_pending_steps = 0;                        // queued steps of the frame that is being abandoned are dropped, like its state
+        m_pending_symbols.clear();
+        m_unreported_renormalisation = 0;
         m_current_decoded_bit = 0;
-        error_t* m = m_metrics.get_old();
+        error_t* m = m_metrics.raw_old();
         for (size_t s = 0; s < NUMSTATES; s++) m[s] = m_config.initial_non_start_error;
         m[starting_state & (NUMSTATES - 1)] = m_config.initial_start_error;
     }
@@ -111,11 +135,49 @@ public:
         assert(get_traceback_length() >= total_bits);
         assert(m_current_decoded_bit >= total_bits + TOTAL_STATE_BITS);
         assert(end_state < NUMSTATES);
-        viterbi_hip_detail::require_ok(vit_hip_chainback_host(m_hip, m_decisions[0], total_bits, end_state, bytes_out),
+        flush_pending();
+        viterbi_hip_detail::require_ok(vit_hip_chainback_host(m_hip, m_decisions.raw_row(0), total_bits, end_state, bytes_out),
                                        "vit_hip_chainback_host");
     }
 
     vit_hip_handle hip_handle() const { return m_hip; }
+
+    // ---- deferred streaming (used by ViterbiDecoder_HIP::update) -------------------------------------------------------------
+    // The reference's streaming callers hand update() the R symbols of ONE trellis step at a time
+    // (examples/helpers/puncture_code_helpers.h:51).  One GPU launch per step would cost 25 us a call; instead short calls are
+    // queued here (a memcpy) and run as ONE vit_hip_update_host when the queue is full, when the cursor reaches the end of the
+    // traceback buffer, or when anything reads the decoder's state (get_error, chainback, m_metrics.get_old(), m_decisions[row]).
+    // m_current_decoded_bit counts queued steps at once.  update()'s return value is the renormalisation sum of every step
+    // COMPUTED since the last value it returned: zero while steps are queued, their whole sum from the call that runs them, so
+    // the caller's running total (accumulated_error += update(...)) is the reference's whenever the queue is empty -- in
+    // particular after the call that completes a frame.
+    static constexpr size_t MAX_PENDING_STEPS = 2048;
+    static constexpr size_t MAX_DEFERRED_CALL_STEPS = 64;     // calls longer than this flush the queue and run directly
+
+    void enqueue_steps(const soft_t* symbols, size_t steps) {
+        m_pending_symbols.insert(m_pending_symbols.end(), symbols, symbols + steps * R);
+        m_pending_steps += steps;
+        m_current_decoded_bit += steps;
+        if (m_pending_steps >= MAX_PENDING_STEPS || m_current_decoded_bit >= m_decisions.size()) flush_pending();
+    }
+    // runs the queued steps; their renormalisation sum is added to what the next update() call returns
+    void flush_pending() {
+        if (m_pending_steps == 0) return;
+        const size_t steps = m_pending_steps, first_row = m_current_decoded_bit - steps;
+        m_pending_steps = 0;                                   // first: the accessors below must not re-enter
+        uint64_t renorm = 0;
+        viterbi_hip_detail::require_ok(
+            vit_hip_update_host(m_hip, m_metrics.raw_old(), m_pending_symbols.data(), steps, m_decisions.raw_row(first_row), &renorm),
+            "vit_hip_update_host");
+        m_pending_symbols.clear();
+        m_unreported_renormalisation += renorm;
+    }
+    uint64_t take_unreported_renormalisation() {
+        const uint64_t v = m_unreported_renormalisation;
+        m_unreported_renormalisation = 0;
+        return v;
+    }
+    size_t pending_steps() const { return m_pending_steps; }
 
 public:
     const BranchTable& m_branch_table;
@@ -125,5 +187,9 @@ public:
     size_t m_current_decoded_bit = 0;
 
 private:
+    static void flush_hook(void* self) { static_cast<ViterbiDecoder_Core*>(self)->flush_pending(); }
     vit_hip_handle m_hip = nullptr;
+    std::vector<soft_t> m_pending_symbols;
+    size_t m_pending_steps = 0;
+    uint64_t m_unreported_renormalisation = 0;
 };

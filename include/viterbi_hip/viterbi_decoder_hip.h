@@ -4,7 +4,9 @@
 // [cursor, cursor + N/R) and m_current_decoded_bit exactly as ViterbiDecoder_Scalar would -- bit for bit, including the
 // strict-'>' tie rule and wrapping error_t arithmetic -- so it slots into the reference's factory lists
 // (examples/helpers/simd_type.h:50-112) next to SCALAR / SIMD_SSE / SIMD_AVX.  May be called repeatedly with any
-// multiple of R symbols (streaming, examples/helpers/puncture_code_helpers.h:51).
+// multiple of R symbols (streaming, examples/helpers/puncture_code_helpers.h:51); calls of up to 64 trellis steps are queued
+// on the host and run on the GPU together (viterbi_decoder_core.h, "deferred streaming"): the state every accessor shows is
+// the reference's, the return value is the renormalisation sum of the steps computed since the last call returned one.
 #pragma once
 #include <type_traits>
 
@@ -28,12 +30,18 @@ public:
         const size_t total_decoded_bits = N / Base::R;
         assert(total_decoded_bits + base.m_current_decoded_bit <= base.get_traceback_length() + Base::TOTAL_STATE_BITS);
         if (total_decoded_bits == 0) return sum_error_t(0);
+        if (total_decoded_bits <= Base::MAX_DEFERRED_CALL_STEPS) {
+            // streaming: queue the steps (ViterbiDecoder_Core::enqueue_steps); they run in one launch with their neighbours
+            base.enqueue_steps(symbols, total_decoded_bits);
+            return sum_error_t(base.take_unreported_renormalisation());
+        }
+        base.flush_pending();
         uint64_t renorm = 0;
         viterbi_hip_detail::require_ok(
-            vit_hip_update_host(base.hip_handle(), base.m_metrics.get_old(), symbols, total_decoded_bits,
-                                base.m_decisions[base.m_current_decoded_bit], &renorm),
+            vit_hip_update_host(base.hip_handle(), base.m_metrics.raw_old(), symbols, total_decoded_bits,
+                                base.m_decisions.raw_row(base.m_current_decoded_bit), &renorm),
             "vit_hip_update_host");
         base.m_current_decoded_bit += total_decoded_bits;
-        return sum_error_t(renorm);
+        return sum_error_t(renorm + base.take_unreported_renormalisation());
     }
 };

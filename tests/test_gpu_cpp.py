@@ -11,7 +11,7 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 
 
 def _ensure_built():
-    if not all(os.path.exists(os.path.join(CPP, n)) for n in ("run_simple_hip", "run_tests_hip", "run_batch_hip", "run_multi_gpu_hip")):
+    if not all(os.path.exists(os.path.join(CPP, n)) for n in ("run_simple_hip", "run_tests_hip", "run_batch_hip", "run_multi_gpu_hip", "run_stream_hip")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
         subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
 
@@ -31,6 +31,18 @@ def test_run_simple_hip():
     p = subprocess.run([os.path.join(CPP, "run_simple_hip")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "error_metric=0" in p.stdout and "0/8192 incorrect bits" in p.stdout
+
+
+@pytest.mark.gpu
+def test_run_stream_hip():
+    """the reference's streaming call pattern (one update() per trellis step) through the header drop-in: queued on the host,
+    run on the GPU in one launch per 2048 steps, every observable equal to one call over the whole stream"""
+    _ensure_built()
+    p = subprocess.run([os.path.join(CPP, "run_stream_hip")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.strip().endswith("PASS")
+    us = float(p.stdout.split(" us per call")[0].split()[-1])
+    assert us < 5.0, p.stdout            # 25 us per call before the queue; about 0.5 us with it
 
 
 @pytest.mark.gpu

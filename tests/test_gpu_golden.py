@@ -58,8 +58,6 @@ def test_batched_route_matches_golden(name, plan):
                                   "k5r2_soft16_3db", "k15r6_soft16_m4db", "k7r2_soft16_2db_l4096", "k15r6_soft16_0db_l256"])
 def test_host_route_mirrors_reference_call_pattern(name, chunk):
     meta, g, pc, table, config = _setup(name)
-    if chunk == 1 and meta["steps"] > 600:
-        pytest.skip("one launch per trellis step: keep to the short fixtures")
     L, R = meta["L"], meta["R"]
     vitdec = ViterbiDecoder_Core(table, config)
     vitdec.set_traceback_length(L)

@@ -122,7 +122,15 @@ def pack_blob(table: ViterbiBranchTable, config: ViterbiDecoder_Config) -> bytes
 
 class ViterbiDecoder_Core:
     """Decoder state with the reference's public surface (viterbi_decoder_core.h:157-243): m_metrics, m_decisions and
-    m_current_decoded_bit are host-visible; update() and chainback() execute on the GPU."""
+    m_current_decoded_bit are host-visible; update() and chainback() execute on the GPU.
+
+    Streamed update() calls (a few trellis steps each: examples/helpers/puncture_code_helpers.h:51 hands over ONE step per
+    call) are queued on the host and run in one launch when the queue is full, when the cursor reaches the end of the traceback
+    buffer, or when anything reads the state (m_metrics, m_decisions, get_error, chainback) -- the same scheme as the C++
+    header include/viterbi_hip/viterbi_decoder_core.h ("deferred streaming")."""
+
+    MAX_PENDING_STEPS = 2048
+    MAX_DEFERRED_CALL_STEPS = 64
 
     def __init__(self, branch_table: ViterbiBranchTable, config: ViterbiDecoder_Config, device: int = 0):
         self.m_branch_table = branch_table
@@ -132,32 +140,74 @@ class ViterbiDecoder_Core:
         self.NUMSTATES = 1 << (self.K - 1)
         self.TOTAL_BLOCKS = max(self.NUMSTATES // 64, 1)
         self._handle = _Handle(branch_table, config, device)
-        self.m_metrics = np.zeros(self.NUMSTATES, dtype=config.error_dtype)
-        self.m_decisions = np.zeros((0, self.TOTAL_BLOCKS), dtype=np.uint64)
+        self._metrics = np.zeros(self.NUMSTATES, dtype=config.error_dtype)
+        self._decisions = np.zeros((0, self.TOTAL_BLOCKS), dtype=np.uint64)
+        self._pending, self._pending_steps, self._unreported = [], 0, 0
         self.m_current_decoded_bit = 0
         self.reset()
         self.set_traceback_length(0)
 
+    # the public data members of the reference: reading them brings the decoder up to date first
+    @property
+    def m_metrics(self):
+        self.flush_pending()
+        return self._metrics
+
+    @property
+    def m_decisions(self):
+        self.flush_pending()
+        return self._decisions
+
     def set_traceback_length(self, traceback_length: int):
+        self.flush_pending()
         new_length = traceback_length + self.TOTAL_STATE_BITS
-        old = self.m_decisions
-        self.m_decisions = np.zeros((new_length, self.TOTAL_BLOCKS), dtype=np.uint64)
+        old = self._decisions
+        self._decisions = np.zeros((new_length, self.TOTAL_BLOCKS), dtype=np.uint64)
         n = min(len(old), new_length)
-        self.m_decisions[:n] = old[:n]
+        self._decisions[:n] = old[:n]
         if self.m_current_decoded_bit > new_length:
             self.m_current_decoded_bit = new_length
 
     def get_traceback_length(self) -> int:
-        return len(self.m_decisions) - self.TOTAL_STATE_BITS
+        return len(self._decisions) - self.TOTAL_STATE_BITS
 
     def get_error(self, end_state: int = 0) -> int:
         assert end_state < self.NUMSTATES
         return int(self.m_metrics[end_state])
 
     def reset(self, starting_state: int = 0):
+        self._pending, self._pending_steps, self._unreported = [], 0, 0     # queued steps of an abandoned frame go with its state
         self.m_current_decoded_bit = 0
-        self.m_metrics[:] = self.m_config.initial_non_start_error
-        self.m_metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
+        self._metrics[:] = self.m_config.initial_non_start_error
+        self._metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
+
+    def _run(self, symbols, steps, first_row):
+        rows = np.zeros((steps, self.TOTAL_BLOCKS), dtype=np.uint64)
+        rs = C.c_uint64(0)
+        _lib.check(_lib.load().vit_hip_update_host(self._handle._h, self._metrics.ctypes.data_as(C.c_void_p),
+                                                   symbols.ctypes.data_as(C.c_void_p), steps, rows.ctypes.data_as(C.c_void_p),
+                                                   C.byref(rs)))
+        self._decisions[first_row:first_row + steps] = rows
+        return int(rs.value)
+
+    def enqueue_steps(self, symbols, steps):
+        self._pending.append(symbols)
+        self._pending_steps += steps
+        self.m_current_decoded_bit += steps
+        if self._pending_steps >= self.MAX_PENDING_STEPS or self.m_current_decoded_bit >= len(self._decisions):
+            self.flush_pending()
+
+    def flush_pending(self):
+        if not self._pending_steps:
+            return
+        steps, self._pending_steps = self._pending_steps, 0
+        symbols = np.ascontiguousarray(np.concatenate(self._pending))
+        self._pending = []
+        self._unreported += self._run(symbols, steps, self.m_current_decoded_bit - steps)
+
+    def take_unreported_renormalisation(self) -> int:
+        v, self._unreported = self._unreported, 0
+        return v
 
     def chainback(self, total_bits: int, end_state: int = 0) -> np.ndarray:
         assert self.get_traceback_length() >= total_bits
@@ -176,7 +226,9 @@ class ViterbiDecoder_HIP:
 
     @staticmethod
     def update(base: ViterbiDecoder_Core, symbols) -> int:
-        cfg = base.m_config
+        """returns the renormalisation sum of the steps COMPUTED since the last value it returned (zero while short calls are
+        queued, their whole sum from the call that runs them): the caller's running total is the reference's whenever nothing is
+        queued -- in particular after the call that completes a frame."""
         symbols = np.ascontiguousarray(symbols, dtype=base.m_branch_table.soft_dtype).reshape(-1)
         N = symbols.size
         assert N % base.R == 0
@@ -185,15 +237,13 @@ class ViterbiDecoder_HIP:
         assert total_decoded_bits + base.m_current_decoded_bit <= max_decoded_bits
         if total_decoded_bits == 0:
             return 0
-        rows = np.zeros((total_decoded_bits, base.TOTAL_BLOCKS), dtype=np.uint64)
-        rs = C.c_uint64(0)
-        _lib.check(_lib.load().vit_hip_update_host(base._handle._h, base.m_metrics.ctypes.data_as(C.c_void_p),
-                                                   symbols.ctypes.data_as(C.c_void_p), total_decoded_bits,
-                                                   rows.ctypes.data_as(C.c_void_p), C.byref(rs)))
-        c = base.m_current_decoded_bit
-        base.m_decisions[c:c + total_decoded_bits] = rows
-        base.m_current_decoded_bit = c + total_decoded_bits
-        return int(rs.value)
+        if total_decoded_bits <= base.MAX_DEFERRED_CALL_STEPS:
+            base.enqueue_steps(symbols.copy(), total_decoded_bits)
+            return base.take_unreported_renormalisation()
+        base.flush_pending()
+        rs = base._run(symbols, total_decoded_bits, base.m_current_decoded_bit)
+        base.m_current_decoded_bit += total_decoded_bits
+        return rs + base.take_unreported_renormalisation()
 
 
 class BatchDecoder:
