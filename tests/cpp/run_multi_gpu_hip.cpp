@@ -2,8 +2,10 @@
 // reference runs one decoder per thread over a shared branch table: examples/run_benchmark.cpp:193-197), an RCCL communicator
 // over all of them, ONE collective -- rank 0's branch table + config broadcast over xGMI (vit_hip_broadcast_table) -- and then
 // every GPU decodes its own contiguous shard of one global batch of frames with no further exchange.
-//   usage: run_multi_gpu_hip [frames_per_gpu] [bits]       (uses every visible GPU; on a one-GPU box the communicator has
-//   one rank and the same code runs)
+//   usage: run_multi_gpu_hip [frames_per_gpu] [bits] [steps]     (uses every visible GPU; on a one-GPU box the communicator
+//   has one rank and the same code runs).  The timed part is `steps` batches through the shipped pipeline API
+//   (ViterbiDecoder_HIP_Pipeline = vit_hip_pipeline_*) per rank; the last line is ONE JSON record in bench.py's schema (value =
+//   aggregate decoded Mbit/s over all GPUs, per-rank rates beside it), so that a node run yields a scaling point from C++ too.
 // Checks: every rank's received table equals rank 0's; noise-free shards decode to exactly what was sent; a noisy shard
 // decodes with a BER in range; shards are disjoint parts of ONE batch (the generator is keyed by the global frame index).
 #include <hip/hip_runtime_api.h>
@@ -27,11 +29,11 @@ struct RankResult {
     int rc = 1;
     bool table_ok = false, clean_ok = false;
     uint64_t noisy_errors = 0;
-    double decode_ms = 0;
+    double decode_ms = 0;          // wall time of the timed pipeline region (all `steps` batches)
     uint8_t first_tx_byte = 0;
 };
 
-static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_t L, RankResult* res) {
+static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_t L, int steps, RankResult* res) {
     HIP_OK(hipSetDevice(rank));
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
@@ -62,13 +64,18 @@ static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_
     dec.synth(frames, L, 42, first_frame, 0.f, true, d_tx, d_sym, st);
     dec.decode(d_sym, frames, L, d_ws, ws_bytes, d_out, nullptr, nullptr, nullptr, st);
     dec.count_bit_errors(d_out, d_tx, frames * out_bytes, d_cnt, st);
-    // noisy shard, timed
+    // noisy shard: `steps` batches through the pipeline, timed from the first submit to the last completion (2 warm-up batches)
     dec.synth(frames, L, 43, first_frame, 3.0f, false, d_tx, d_sym, st);
     HIP_OK(hipStreamSynchronize(st));
-    const auto t0 = std::chrono::steady_clock::now();
-    dec.decode(d_sym, frames, L, d_ws, ws_bytes, d_out, nullptr, nullptr, nullptr, st);
-    HIP_OK(hipStreamSynchronize(st));
-    res->decode_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
+    {
+        ViterbiDecoder_HIP_Pipeline<K, R, uint16_t, int16_t> pipe(dec, frames, L);
+        for (int k = 0; k < 2; k++) pipe.submit(d_sym, frames, d_out);
+        pipe.sync();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < steps; k++) pipe.submit(d_sym, frames, d_out);
+        pipe.sync();
+        res->decode_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
+    }
     dec.count_bit_errors(d_out, d_tx, frames * out_bytes, d_cnt + 1, st);
     uint64_t cnt[2];
     HIP_OK(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -85,6 +92,7 @@ static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_
 
 int main(int argc, char** argv) {
     const size_t frames = argc > 1 ? size_t(atol(argv[1])) : 8192, L = argc > 2 ? size_t(atol(argv[2])) : 2048;
+    const int steps = argc > 3 ? atoi(argv[3]) : 10;
     int n = 0;
     HIP_OK(hipGetDeviceCount(&n));
     if (n < 1) { printf("no GPU\n"); return 1; }
@@ -94,20 +102,28 @@ int main(int argc, char** argv) {
     if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) { printf("ncclCommInitAll failed\n"); return 1; }
     std::vector<RankResult> res(n);
     std::vector<std::thread> th;
-    for (int r = 0; r < n; r++) th.emplace_back(rank_main, r, n, comms[r], frames, L, &res[r]);
+    for (int r = 0; r < n; r++) th.emplace_back(rank_main, r, n, comms[r], frames, L, steps, &res[r]);
     for (auto& t : th) t.join();
     for (int r = 0; r < n; r++) ncclCommDestroy(comms[r]);
     bool ok = true;
-    double total_bits = 0, max_ms = 0;
+    double max_ms = 0;
     for (int r = 0; r < n; r++) {
         const double ber = double(res[r].noisy_errors) / double(frames * L);
-        printf("rank %d: table %s, noise-free shard %s, noisy shard BER %.2e, decode %.3f ms\n", r, res[r].table_ok ? "ok" : "BAD",
-               res[r].clean_ok ? "exact" : "WRONG", ber, res[r].decode_ms);
+        printf("rank %d: table %s, noise-free shard %s, noisy shard BER %.2e, %d batches in %.3f ms = %.1f Mbit/s\n", r,
+               res[r].table_ok ? "ok" : "BAD", res[r].clean_ok ? "exact" : "WRONG", ber, steps, res[r].decode_ms,
+               double(frames * L) * steps / res[r].decode_ms / 1e3);
         ok = ok && res[r].rc == 0 && res[r].table_ok && res[r].clean_ok && ber > 0 && ber < 2e-3;
-        total_bits += double(frames * L);
         max_ms = res[r].decode_ms > max_ms ? res[r].decode_ms : max_ms;
     }
-    printf("gpus=%d frames/gpu=%zu bits/frame=%zu aggregate %.1f Gbit/s (slowest rank)\n", n, frames, L, total_bits / max_ms / 1e6);
+    // one record in bench.py's schema: whole-job throughput over the slowest rank's wall time (ranks start together: one thread each)
+    const double value = double(frames * L) * steps * n / max_ms / 1e3;
+    printf("{\"metric\": \"decoded Mbit/s (= ACS trellis steps/s), update()+chainback()\", \"value\": %.1f, \"unit\": \"Mbit/s\", "
+           "\"n_gpus\": %d, \"steps\": %d, \"warmup\": 2, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", "
+           "\"vs_baseline\": null, \"dtype\": \"u16\", \"data\": \"synthetic\", \"config\": {\"workload\": \"Voyager K=7 R=1/2 SOFT16, "
+           "%zu frames x %zu info bits per GPU, AWGN Eb/N0=3 dB\", \"host\": \"tests/cpp/run_multi_gpu_hip (C++, one thread per GPU, "
+           "RCCL broadcast of the table, vit_hip_pipeline_*)\"}, \"per_rank_Mbit_s\": [", value, n, steps, max_ms / steps, frames, L);
+    for (int r = 0; r < n; r++) printf("%s%.1f", r ? ", " : "", double(frames * L) * steps / res[r].decode_ms / 1e3);
+    printf("]}\n");
     printf("%s\n", ok ? "PASS" : "FAIL");
     return ok ? 0 : 1;
 }

@@ -73,3 +73,8 @@ def test_run_multi_gpu_hip():
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert "table ok" in p.stdout and "BAD" not in p.stdout and p.stdout.strip().endswith("PASS")
+    # the line before PASS is one record in bench.py's schema (a node run gives a scaling point from C++ too)
+    import json
+    rec = json.loads(p.stdout.strip().splitlines()[-2])
+    assert rec["unit"] == "Mbit/s" and rec["n_gpus"] >= 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert len(rec["per_rank_Mbit_s"]) == rec["n_gpus"] and abs(sum(rec["per_rank_Mbit_s"]) - rec["value"]) < 0.35 * rec["value"]
