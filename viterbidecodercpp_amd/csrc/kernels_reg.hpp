@@ -832,6 +832,7 @@ struct RegChainbackArgs {
     uint8_t* out;             // [F][ceil(L/8)]
     const u32* end_state;     // [F] or null
     u32 frames, L;
+    u32 wave_priority;        // != 0: raise the waves' issue priority above the update kernel's (s_setprio 3)
 };
 
 template <class SP>
@@ -1225,7 +1226,12 @@ VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
 template <class SP>
 constexpr unsigned reg_chainback_frames_per_block() { return SP::NREG == 16 && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
 template <class SP>
-__global__ void __launch_bounds__(64, 2) reg_chainback_kernel(RegChainbackArgs a) { reg_chainback_body<SP>(a); }
+__global__ void __launch_bounds__(64, 2) reg_chainback_kernel(RegChainbackArgs a) {
+    // beside TWO update kernels (the small-batch pipeline schedule) the bit chase would otherwise get the issue slots both leave
+    // over and become the pipeline's bottleneck: there it runs at the higher wave priority
+    if (a.wave_priority) __builtin_amdgcn_s_setprio(3);
+    reg_chainback_body<SP>(a);
+}
 template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 
@@ -1396,7 +1402,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
 }
 
 inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
-                         hipStream_t st) {
+                         hipStream_t st, unsigned wave_priority = 0) {
     if (frames == 0 || L == 0) return 0;
     RegChainbackArgs a{};
     a.ws = (const uint4*)d_ws;
@@ -1405,6 +1411,7 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.end_state = d_end;
     a.frames = (u32)frames;
     a.L = (u32)L;
+    a.wave_priority = wave_priority;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     if (rc.jit) {
         const unsigned fpb = rc.jit->chainback_frames_per_block;

@@ -183,7 +183,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, false>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, 2) vit_jit_chainback(vit::RegChainbackArgs a) { vit::reg_chainback_body<SP>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, 2) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
         }
         const std::string tmp = hsaco + "." + std::to_string((long)getpid()) + ".tmp";

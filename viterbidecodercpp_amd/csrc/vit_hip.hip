@@ -522,8 +522,8 @@ int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t 
                              d_metrics_inout, d_metrics_inout, d_renorm_sum, nullptr, stream);
 }
 
-int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
-                            const uint32_t* d_end_state, vit_hip_stream_t stream) {
+static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (frames == 0 || L == 0) return VIT_HIP_OK;
     if (!d_workspace || !d_bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "d_workspace/d_bytes_out is NULL");
@@ -531,7 +531,7 @@ int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t fr
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (h->plan == VIT_HIP_PLAN_REG) {
-        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st);
+        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
         return VIT_HIP_OK;
     }
@@ -541,6 +541,11 @@ int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t fr
         return VIT_HIP_OK;
     }
     return lds_chainback(h, (const uint64_t*)d_workspace, frames, L, d_bytes_out, d_end_state, st);
+}
+
+int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                            const uint32_t* d_end_state, vit_hip_stream_t stream) {
+    return chainback_batch_impl(h, d_workspace, frames, L, d_bytes_out, d_end_state, stream, 0);
 }
 
 int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t L, void* d_workspace,
@@ -617,6 +622,7 @@ struct vit_hip_pipeline {
     unsigned long long n = 0;
     size_t overlap_max_frames = 0;      // largest batch whose chainback is worth running beside the next update
     size_t two_updates_max_frames = 0;  // largest batch that leaves room for a second update kernel beside the first
+    unsigned cb_wave_priority = 0;      // two-update schedule: the chainback kernel outranks the update waves
     // optional per-batch timing (vit_hip_pipeline_set_timing): four events per submitted batch, resolved by sync()
     bool timing = false;
     struct Rec { hipEvent_t u0, u1, c0, c1; };
@@ -670,6 +676,8 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     }
     p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
     p->n_ws = p->n_upd + 1;
+    p->cb_wave_priority = p->n_upd > 1 ? 1u : 0u;
+    if (const char* e = getenv("VIT_HIP_PIPELINE_CB_PRIO")) p->cb_wave_priority = *e == '1' ? 1u : 0u;   // experiments only
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
     bool ok = hipStreamCreateWithPriority(&p->s_cb, hipStreamNonBlocking, hi) == hipSuccess;   // the short bit chase gets out of the update's way
@@ -718,7 +726,7 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
         VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
     }
     if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
-    rc = vit_hip_chainback_batch(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, s_cb);
+    rc = chainback_batch_impl(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, s_cb, p->cb_wave_priority);
     if (rc != VIT_HIP_OK) return rc;
     if (p->timing) {
         VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
