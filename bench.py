@@ -240,10 +240,13 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
     ocfg = pyoracle.stock_config(dt, code.R)
     n = max(1, min(F, n if code.K < 11 else 2))
     S = L + code.K - 1
-    # the workspace layout is tile-major: export the first frames only
-    got_dec = last_decisions(n).cpu().numpy().view(np.uint64)
-    got_bytes = out_dev[:n].cpu().numpy()
-    sym = sym_dev[:n].cpu().numpy()
+    # the workspace layout is tile-major: export the first frames of the last launch only (with sub-batches that launch holds
+    # frames f0 .. of the batch)
+    f0, got_dec = last_decisions(n)
+    got_dec = got_dec.cpu().numpy().view(np.uint64)
+    n = got_dec.shape[0]
+    got_bytes = out_dev[f0:f0 + n].cpu().numpy()
+    sym = sym_dev[f0:f0 + n].cpu().numpy()
     ref = pyoracle.RefLib() if pyoracle.RefLib.available() else None
     oracle = None if ref else pyoracle.Oracle()
     ok_b = ok_d = True
@@ -255,7 +258,7 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
         ok_b = ok_b and np.array_equal(got_bytes[f], w["bytes"])
         ok_d = ok_d and np.array_equal(got_dec[f], w["decisions"][:S])
     torch.cuda.synchronize()
-    return {"frames_checked_vs_scalar_reference": int(n), "checker": "reference (oracle/_ref)" if ref else "port (oracle/)",
+    return {"frames_checked_vs_scalar_reference": int(n), "first_frame_checked": int(f0), "checker": "reference (oracle/_ref)" if ref else "port (oracle/)",
             "chainback_bytes_bit_exact": bool(ok_b), "decision_words_bit_exact": bool(ok_d), "bit_exact": bool(ok_b and ok_d)}
 
 
@@ -367,11 +370,18 @@ def main():
         elapsed_local = time.perf_counter() - t0
         clock_after = shader_clock()
         t_upd, t_cb, t_done = pipe.timing()
-        assert len(t_upd) == args.steps
-        upd_ms, cb_ms = float(np.mean(t_upd)), float(np.mean(t_cb))
-        step_times = np.diff(np.concatenate([[0.0], t_done.astype(np.float64)]))
+        # one record per SUB-batch (the library may feed a batch to the kernels in several launches: sch.sub_batch_frames)
+        F_launch = min(F, int(sch.sub_batch_frames))
+        per_step = -(-F // F_launch)
+        assert len(t_upd) == args.steps * per_step
+        upd_ms, cb_ms = float(np.mean(t_upd)), float(np.mean(t_cb))        # per launch
+        step_times = np.diff(np.concatenate([[0.0], t_done.astype(np.float64)[per_step - 1::per_step]]))
+        if per_step > 1:
+            sched_desc += f", each batch in {per_step} sub-batches of {F_launch} frames"
+        if sch.chainback_wave_priority:
+            sched_desc += ", chainback at the higher wave priority"
 
-        def last_decisions(n):            # decision rows of the LAST timed step, straight from the pipeline's workspace
+        def last_decisions(n):            # decision rows of the LAST timed launch, straight from the pipeline's workspace
             return pipe.export_last_decisions(n)
     else:
         # ---- A/B: the same schedule from Python.  Decision workspaces and HIP streams as vit_hip_pipeline_create picks them:
@@ -435,8 +445,10 @@ def main():
         t_done = np.asarray([evs[0][0].elapsed_time(e[2]) for e in evs], dtype=np.float64)
         step_times = np.diff(np.concatenate([[0.0], t_done]))
 
+        F_launch = F
+
         def last_decisions(n):
-            return dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
+            return 0, dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
 
     elapsed = elapsed_local
     per_rank = [float(F) * L * args.steps / elapsed_local / 1e6]
@@ -462,12 +474,13 @@ def main():
     value = total_bits / elapsed / 1e6
     step_ms = elapsed / args.steps * 1e3
     sb = pc.soft_bytes
-    upd_bytes = F * (S * code.R * sb + S * W * 8)            # symbols read + decision words written
+    upd_bytes = F * (S * code.R * sb + S * W * 8)            # symbols read + decision words written, one step
     cb_bytes = F * (L * 8 + L // 8)                          # one decision word read per decoded bit + bytes out
-    achieved = upd_bytes / (upd_ms * 1e-3) / 1e9
+    upd_bytes_launch = F_launch * (S * code.R * sb + S * W * 8)     # ... and one LAUNCH (a step may be several: sub-batches)
+    achieved = upd_bytes_launch / (upd_ms * 1e-3) / 1e9
     traffic, traffic_src, valu_insts = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    key = f"{code.name}|{args.decode_type}|{F}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
+    key = f"{code.name}|{args.decode_type}|{F_launch}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath)).get(key, {})
@@ -477,7 +490,7 @@ def main():
         except Exception:
             traffic = None
 
-    state_updates = float(F) * S * code.num_states            # add-compare-select results per launch
+    state_updates = float(F_launch) * S * code.num_states     # add-compare-select results per launch
     result = {
         "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
         "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -502,7 +515,7 @@ def main():
                       "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]]},
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes_launch, "frames_per_launch": F_launch,
                      # `achieved` is per launch as the contract defines it.  With two update launches in flight (the small-batch
                      # schedule) each one takes about twice as long while the SIMDs do the work of both: the kernel's rate over
                      # the timed region, all launches together, is the second figure
@@ -526,7 +539,7 @@ def main():
         ns = rates["packed16_ns_per_wave_instr_per_simd"]
         waves = None
         if dec.plan == _lib.PLAN_REG:
-            waves = -(-F // tile_frames) / float(N_SIMD) * NUPD
+            waves = -(-F_launch // tile_frames) / float(N_SIMD) * NUPD
         wkey = "4" if waves is None else str(int(min(4, max(1, -(-waves // 1)))))
         peak_measured = N_SIMD / ns[wkey]                                  # G wave-instructions per second over the chip
         peak_spec = N_SIMD * rates["spec_clock_ghz"] / rates["spec_cycles_per_wave64_instr"]

@@ -173,6 +173,11 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  *   - register plan, at most ONE update wave per SIMD (max_frames <= 4 x CUs x workspace_tile_frames: the 32768-frame share
  *     of an 8-GPU run): THREE workspaces and TWO update streams, so that two update kernels share the SIMDs (a lone wave
  *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream;
+ *     (and the chainback kernel at a higher wave priority than the updates: between two staggered update kernels it would
+ *     otherwise get the issue slots both leave over and become the bottleneck);
+ *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9): a batch of up
+ *     to two waves per SIMD is fed to the kernels as SUB-BATCHES of one wave per SIMD through the same three-workspace,
+ *     two-update-stream schedule (K = 9, 65536 frames: 14.2 -> 12.0 ms per batch);
  *   - larger batches and the LDS plans fill the CUs by themselves, a chainback in their way costs more than it hides:
  *     one stream, update and chainback back to back. */
 typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
@@ -180,10 +185,12 @@ typedef struct vit_hip_pipeline_schedule {
     int32_t workspaces;             /* decision workspaces owned (2 or 3) */
     int32_t update_streams;         /* update kernels that may be in flight at once (1 or 2) */
     int32_t chainback_overlapped;   /* 1: chainbacks run on their own stream beside the next update; 0: back to back */
-    int32_t reserved;
+    int32_t chainback_wave_priority;/* 1: the chainback kernel runs at a higher wave priority than the update kernels */
     size_t overlap_max_frames;      /* largest batch whose chainback is overlapped */
-    size_t two_updates_max_frames;  /* largest max_frames that gets the two-update schedule */
+    size_t two_updates_max_frames;  /* largest max_frames that gets the two-update schedule without sub-batches */
     size_t workspace_bytes_each;
+    size_t sub_batch_frames;        /* a submitted batch reaches the kernels in sub-batches of at most this many frames
+                                       (= max_frames unless the schedule splits); timing records are per sub-batch */
 } vit_hip_pipeline_schedule;
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
@@ -191,13 +198,14 @@ int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t 
 int vit_hip_pipeline_sync(vit_hip_pipeline_t p);
 int vit_hip_pipeline_destroy(vit_hip_pipeline_t p);
 int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* schedule);
-/* the decision workspace of the most recently submitted batch (vit_hip_export_decisions reads the history from it): valid
- * after a sync() and until the next submit(); owned by the pipeline. */
-int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace);
+/* the decision workspace of the most recently submitted (sub-)batch and the frame range of the submitted batch it holds
+ * (vit_hip_export_decisions reads the history from it; first_frame / frames may be NULL): valid after a sync() and until the
+ * next submit(); owned by the pipeline. */
+int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace, size_t* first_frame, size_t* frames);
 /* Per-batch timing with HIP events on the streams the kernels run on (the reference times its two phases separately:
  * examples/run_benchmark.cpp:272-281).  set_timing(p, 1) synchronises, clears the records and starts recording every
  * submitted batch; set_timing(p, 0) stops.  get_timing() returns, for the batches completed by the last sync(), in submit
- * order: the update kernel's duration, the chainback kernel's duration, and the time at which the batch's chainback finished
+ * order (one record per SUB-batch: vit_hip_pipeline_schedule.sub_batch_frames): the update kernel's duration, the chainback kernel's duration, and the time at which the batch's chainback finished
  * measured from the start of the first recorded update (all in ms; consecutive differences of complete_ms are the
  * pipeline's per-batch step times).  Arrays may be NULL; at most `capacity` entries are written, *n_batches is the count. */
 int vit_hip_pipeline_set_timing(vit_hip_pipeline_t p, int enable);

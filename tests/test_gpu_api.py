@@ -208,6 +208,7 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
     (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
     (7, "SOFT16", 24, 256, (2, 1, 0)),       # K = 15 (PLAN_LDS2): back to back
+    (5, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9: two update waves fill a SIMD's registers, so the batch goes in sub-batches of 32768
 ])
 def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want):
     """vit_hip_pipeline_*: whatever schedule the library picks (two updates in flight, chainback beside the next update, or
@@ -229,7 +230,10 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     assert lib.vit_hip_pipeline_get_schedule(pipe, C.byref(sch)) == _lib.OK
     if want is not None:
         assert (sch.workspaces, sch.update_streams, sch.chainback_overlapped) == want
-    assert sch.workspace_bytes_each == dec.workspace_bytes(F, L)
+    sub = int(sch.sub_batch_frames)
+    if want is not None:
+        assert sub == (32768 if code_id == 5 else F) and sch.chainback_wave_priority == (1 if sch.update_streams == 2 else 0)
+    assert sch.workspace_bytes_each == dec.workspace_bytes(min(F, sub), L)
     assert lib.vit_hip_pipeline_set_timing(pipe, 1) == _lib.OK
     batches, outs = [], []
     for k in range(7):
@@ -246,20 +250,24 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     for (n, sym, tx), out in zip(batches, outs):
         assert torch.equal(out, dec.decode(sym, L))
     # the last batch's decision rows are readable from the pipeline's own workspace
-    ws = C.c_void_p()
-    assert lib.vit_hip_pipeline_last_workspace(pipe, C.byref(ws)) == _lib.OK
-    n_last = min(batches[-1][0], 64)
+    ws, f0, nf = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+    assert lib.vit_hip_pipeline_last_workspace(pipe, C.byref(ws), C.byref(f0), C.byref(nf)) == _lib.OK
+    n_all = batches[-1][0]
+    assert f0.value + nf.value == n_all and nf.value == n_all - (n_all - 1) // sub * sub     # the last sub-batch of the last batch
+    n_last = min(nf.value, 64)
     got = torch.empty((n_last, L + code.K - 1, dec.W), dtype=torch.int64, device="cuda")
     assert lib.vit_hip_export_decisions(dec._handle._h, ws, n_last, L + code.K - 1, L, C.c_void_p(got.data_ptr()), None) == _lib.OK
-    dec.update(batches[-1][1], L)
+    dec.update(batches[-1][1][f0.value:].contiguous(), L)
     assert torch.equal(got, dec.export_decisions(n_last, L))
-    # timing: one record per batch, in order, completion times non-decreasing
+    # timing: one record per (sub-)batch, in order, completion times non-decreasing
+    n_rec_want = sum(-(-n // sub) for n, _, _ in batches)
     nrec = C.c_size_t(0)
-    u, c, d = (np.zeros(16, dtype=np.float32) for _ in range(3))
+    u, c, d = (np.zeros(32, dtype=np.float32) for _ in range(3))
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    assert lib.vit_hip_pipeline_get_timing(pipe, 16, p(u), p(c), p(d), C.byref(nrec)) == _lib.OK
-    assert nrec.value == len(batches)
-    assert (u[:7] > 0).all() and (c[:7] > 0).all() and (np.diff(d[:7]) >= 0).all() and d[0] >= u[0]
+    assert lib.vit_hip_pipeline_get_timing(pipe, 32, p(u), p(c), p(d), C.byref(nrec)) == _lib.OK
+    assert nrec.value == n_rec_want
+    k = n_rec_want
+    assert (u[:k] > 0).all() and (c[:k] > 0).all() and (np.diff(d[:k]) >= 0).all() and d[0] >= u[0]
     assert lib.vit_hip_pipeline_set_timing(pipe, 0) == _lib.OK
     assert lib.vit_hip_pipeline_get_timing(pipe, 0, None, None, None, C.byref(nrec)) == _lib.OK and nrec.value == 0
     assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK

@@ -38,8 +38,8 @@ class VitHipInfo(C.Structure):
 
 class VitHipPipelineSchedule(C.Structure):
     _fields_ = [("workspaces", C.c_int32), ("update_streams", C.c_int32), ("chainback_overlapped", C.c_int32),
-                ("reserved", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
-                ("workspace_bytes_each", C.c_size_t)]
+                ("chainback_wave_priority", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
+                ("workspace_bytes_each", C.c_size_t), ("sub_batch_frames", C.c_size_t)]
 
 
 class VitHipError(RuntimeError):
@@ -95,7 +95,7 @@ def load():
     L.vit_hip_pipeline_sync.argtypes = [vp]
     L.vit_hip_pipeline_destroy.argtypes = [vp]
     L.vit_hip_pipeline_get_schedule.argtypes = [vp, C.POINTER(VitHipPipelineSchedule)]
-    L.vit_hip_pipeline_last_workspace.argtypes = [vp, C.POINTER(vp)]
+    L.vit_hip_pipeline_last_workspace.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.vit_hip_pipeline_set_timing.argtypes = [vp, i32]
     L.vit_hip_pipeline_get_timing.argtypes = [vp, sz, vp, vp, vp, C.POINTER(sz)]
     L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]

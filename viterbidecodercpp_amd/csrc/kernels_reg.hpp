@@ -1310,6 +1310,8 @@ template <> struct RegSpecOf<6> { using type = Spec_K5R2; };
 template <int ID> int reg_launch_update(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st);
 template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st);
 template <int ID> int reg_launch_export(const RegExportArgs& a, unsigned blocks, hipStream_t st);
+// vector registers (arch + accumulation) one wave of the update / chainback kernel holds: what decides which kernels can share a SIMD
+template <int ID> int reg_query_vgprs(int shift, int* update_regs, int* chainback_regs);
 
 #ifdef VIT_REG_ID
 template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st) {
@@ -1334,6 +1336,17 @@ template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned b
     hipLaunchKernelGGL(reg_export_kernel<SP>, dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+template <> int reg_query_vgprs<VIT_REG_ID>(int shift, int* update_regs, int* chainback_regs) {
+    using SP = RegSpecOf<VIT_REG_ID>::type;
+    hipFuncAttributes fu{}, fc{};
+    const hipError_t e1 = shift ? hipFuncGetAttributes(&fu, reinterpret_cast<const void*>(reg_update_kernel<SP, 8>))
+                                : hipFuncGetAttributes(&fu, reinterpret_cast<const void*>(reg_update_kernel<SP, 0>));
+    const hipError_t e2 = hipFuncGetAttributes(&fc, reinterpret_cast<const void*>(reg_chainback_kernel<SP>));
+    if (e1 != hipSuccess || e2 != hipSuccess) return -1;
+    *update_regs = fu.numRegs;
+    *chainback_regs = fc.numRegs;
+    return 0;
+}
 #else
 template <> int reg_launch_update<0>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_update<1>(int, const RegUpdateArgs&, unsigned, hipStream_t);
@@ -1356,6 +1369,39 @@ template <> int reg_launch_export<3>(const RegExportArgs&, unsigned, hipStream_t
 template <> int reg_launch_export<4>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<5>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<6>(const RegExportArgs&, unsigned, hipStream_t);
+template <> int reg_query_vgprs<0>(int, int*, int*);
+template <> int reg_query_vgprs<1>(int, int*, int*);
+template <> int reg_query_vgprs<2>(int, int*, int*);
+template <> int reg_query_vgprs<3>(int, int*, int*);
+template <> int reg_query_vgprs<4>(int, int*, int*);
+template <> int reg_query_vgprs<5>(int, int*, int*);
+template <> int reg_query_vgprs<6>(int, int*, int*);
+
+// can two update waves and one chainback wave of this code share a SIMD (512 registers per lane, allocated in granules of 8)?
+// When they cannot (K = 9: two update waves take all 512), the chainback of a batch only runs in the gaps between update
+// kernels, and the pipeline does better feeding the SIMDs half-size sub-batches from two streams.
+inline bool reg_chainback_fits_beside_two_updates(const RegCode& rc, int shift) {
+    int ur = 0, cr = 0, ok = -1;
+    if (rc.jit) {
+        hipFunction_t fu = rc.jit->update[shift ? 1 : 0], fc = rc.jit->chainback;
+        ok = (hipFuncGetAttribute(&ur, HIP_FUNC_ATTRIBUTE_NUM_REGS, fu) == hipSuccess &&
+              hipFuncGetAttribute(&cr, HIP_FUNC_ATTRIBUTE_NUM_REGS, fc) == hipSuccess) ? 0 : -1;
+    } else {
+        switch (rc.id) {
+            case 0: ok = reg_query_vgprs<0>(shift, &ur, &cr); break;
+            case 1: ok = reg_query_vgprs<1>(shift, &ur, &cr); break;
+            case 2: ok = reg_query_vgprs<2>(shift, &ur, &cr); break;
+            case 3: ok = reg_query_vgprs<3>(shift, &ur, &cr); break;
+            case 4: ok = reg_query_vgprs<4>(shift, &ur, &cr); break;
+            case 5: ok = reg_query_vgprs<5>(shift, &ur, &cr); break;
+            case 6: ok = reg_query_vgprs<6>(shift, &ur, &cr); break;
+            default: break;
+        }
+    }
+    if (ok != 0 || ur <= 0 || cr <= 0) return rc.K < 9;          // the runtime would not say: the stock kernels' answer
+    auto alloc = [](int r) { return (r + 7) / 8 * 8; };
+    return 2 * alloc(ur) + alloc(cr) <= 512;
+}
 
 inline int reg_jit_launch(hipFunction_t fn, const void* args, size_t args_bytes, unsigned grid, unsigned block, hipStream_t st) {
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_bytes,

@@ -623,6 +623,9 @@ struct vit_hip_pipeline {
     size_t overlap_max_frames = 0;      // largest batch whose chainback is worth running beside the next update
     size_t two_updates_max_frames = 0;  // largest batch that leaves room for a second update kernel beside the first
     unsigned cb_wave_priority = 0;      // two-update schedule: the chainback kernel outranks the update waves
+    size_t sub_frames = 0;              // a submitted batch is fed to the kernels in sub-batches of at most this many frames
+    size_t last_first_frame = 0, last_frames = 0;   // frame range of the most recent sub-batch (the one ws[(n-1) % n_ws] holds)
+    size_t sym_frame_bytes = 0, out_frame_bytes = 0;
     // optional per-batch timing (vit_hip_pipeline_set_timing): four events per submitted batch, resolved by sync()
     bool timing = false;
     struct Rec { hipEvent_t u0, u1, c0, c1; };
@@ -655,7 +658,6 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     vit_hip_pipeline* p = new (std::nothrow) vit_hip_pipeline();
     if (!p) return fail(VIT_HIP_ERR_RUNTIME, "out of host memory");
     p->h = h; p->max_frames = max_frames; p->L = L;
-    p->ws_bytes = vit_hip_workspace_bytes(h, max_frames, L);
     // Rule 1 -- chainback beside the next update.  The overlap pays while the update leaves register file and issue slots
     // free: PLAN_REG with at most two update waves per SIMD (a 140-register wave; the chainback's 166 make a third resident).
     // A larger batch fills the SIMDs by itself, and the PLAN_LDS2 / PLAN_LDS update takes whole CUs: there a chainback in the
@@ -674,8 +676,24 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
         if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
     }
+    // Rule 3 -- sub-batches.  Where two update waves leave no registers for a chainback wave (K = 9: 2 x 256 of the SIMD's 512),
+    // the chainback of a two-waves-per-SIMD batch cannot run beside the next update at all: such a batch is fed to the kernels
+    // as sub-batches of one update wave per SIMD from the two update streams (K9 65536 x 8192: 14.2 -> 12.0 ms).
+    p->sub_frames = max_frames;
     p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
+    if (h->plan == VIT_HIP_PLAN_REG && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames &&
+        !vit::reg_chainback_fits_beside_two_updates(h->reg_code, h->shift)) {
+        p->sub_frames = p->two_updates_max_frames;
+        p->n_upd = 2;
+    }
+    if (const char* e = getenv("VIT_HIP_PIPELINE_SPLIT")) {     // experiments only: 1 forces sub-batches, 0 forbids them
+        if (*e == '1' && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames) { p->sub_frames = p->two_updates_max_frames; p->n_upd = 2; }
+        if (*e == '0' && p->sub_frames < max_frames) { p->sub_frames = max_frames; p->n_upd = 1; }
+    }
     p->n_ws = p->n_upd + 1;
+    p->ws_bytes = vit_hip_workspace_bytes(h, p->sub_frames, L);
+    p->sym_frame_bytes = (L + (size_t)h->K - 1) * (size_t)h->R * (size_t)h->soft_bytes;
+    p->out_frame_bytes = (L + 7) / 8;
     p->cb_wave_priority = p->n_upd > 1 ? 1u : 0u;
     if (const char* e = getenv("VIT_HIP_PIPELINE_CB_PRIO")) p->cb_wave_priority = *e == '1' ? 1u : 0u;   // experiments only
     int lo = 0, hi = 0;
@@ -701,41 +719,50 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
     if (frames == 0) return VIT_HIP_OK;
     DeviceGuard guard(p->h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
-    const int k = (int)(p->n % (unsigned long long)p->n_ws);
-    hipStream_t s_upd = p->s_upd[(int)(p->n % (unsigned long long)p->n_upd)];
-    vit_hip_pipeline::Rec rec{nullptr, nullptr, nullptr, nullptr};
-    if (p->timing) {
-        rec.u0 = pipe_event(p); rec.u1 = pipe_event(p); rec.c0 = pipe_event(p); rec.c1 = pipe_event(p);
-        if (!rec.u0 || !rec.u1 || !rec.c0 || !rec.c1) return fail(VIT_HIP_ERR_RUNTIME, "hipEventCreate failed");
+    // a batch goes to the kernels in sub-batches of at most sub_frames frames (one, unless pipeline_create chose to split)
+    for (size_t f0 = 0; f0 < frames; f0 += p->sub_frames) {
+        const size_t nf = frames - f0 < p->sub_frames ? frames - f0 : p->sub_frames;
+        const bool last = f0 + nf >= frames;
+        const uint8_t* sym = (const uint8_t*)d_symbols + f0 * p->sym_frame_bytes;
+        uint8_t* out = d_bytes_out + f0 * p->out_frame_bytes;
+        const uint32_t* es = d_end_state ? d_end_state + f0 : nullptr;
+        const int k = (int)(p->n % (unsigned long long)p->n_ws);
+        hipStream_t s_upd = p->s_upd[(int)(p->n % (unsigned long long)p->n_upd)];
+        vit_hip_pipeline::Rec rec{nullptr, nullptr, nullptr, nullptr};
+        if (p->timing) {
+            rec.u0 = pipe_event(p); rec.u1 = pipe_event(p); rec.c0 = pipe_event(p); rec.c1 = pipe_event(p);
+            if (!rec.u0 || !rec.u1 || !rec.c0 || !rec.c1) return fail(VIT_HIP_ERR_RUNTIME, "hipEventCreate failed");
+        }
+        // the chainback that last read this workspace must have finished before the update overwrites it
+        if (p->cb_pending[k]) VIT_HIP_CHECK(hipStreamWaitEvent(s_upd, p->cb_done[k], 0));
+        if (p->timing) {
+            VIT_HIP_CHECK(hipEventRecord(rec.u0, s_upd));
+            if (!p->epoch) p->epoch = rec.u0;
+        }
+        int rc = vit_hip_update_batch(p->h, sym, nf, p->L + (size_t)p->h->K - 1, p->L, p->ws[k], p->ws_bytes, nullptr, nullptr, nullptr, s_upd);
+        if (rc != VIT_HIP_OK) return rc;
+        if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.u1, s_upd));
+        hipStream_t s_cb = s_upd;                                   // back to back unless the overlap pays (pipeline_create)
+        if (frames <= p->overlap_max_frames || p->n_upd > 1) {
+            // all chainbacks go through ONE stream: batches complete in submit order whichever update stream fed them
+            s_cb = p->s_cb;
+            VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], s_upd));
+            VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
+        }
+        if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
+        rc = chainback_batch_impl(p->h, p->ws[k], nf, p->L, out, es, s_cb, p->cb_wave_priority);
+        if (rc != VIT_HIP_OK) return rc;
+        if (p->timing) {
+            VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
+            p->pending_recs.push_back(rec);
+        }
+        VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], s_cb));
+        if (done_event && last) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, s_cb));
+        p->cb_pending[k] = true;
+        p->last_first_frame = f0;
+        p->last_frames = nf;
+        p->n++;
     }
-    // the chainback that last read this workspace must have finished before the update overwrites it
-    if (p->cb_pending[k]) VIT_HIP_CHECK(hipStreamWaitEvent(s_upd, p->cb_done[k], 0));
-    if (p->timing) {
-        VIT_HIP_CHECK(hipEventRecord(rec.u0, s_upd));
-        if (!p->epoch) p->epoch = rec.u0;
-    }
-    int rc = vit_hip_update_batch(p->h, d_symbols, frames, p->L + (size_t)p->h->K - 1, p->L, p->ws[k], p->ws_bytes, nullptr, nullptr,
-                                  nullptr, s_upd);
-    if (rc != VIT_HIP_OK) return rc;
-    if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.u1, s_upd));
-    hipStream_t s_cb = s_upd;                                   // back to back unless the overlap pays (pipeline_create)
-    if (frames <= p->overlap_max_frames || p->n_upd > 1) {
-        // all chainbacks go through ONE stream: batches complete in submit order whichever update stream fed them
-        s_cb = p->s_cb;
-        VIT_HIP_CHECK(hipEventRecord(p->upd_done[k], s_upd));
-        VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
-    }
-    if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
-    rc = chainback_batch_impl(p->h, p->ws[k], frames, p->L, d_bytes_out, d_end_state, s_cb, p->cb_wave_priority);
-    if (rc != VIT_HIP_OK) return rc;
-    if (p->timing) {
-        VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
-        p->pending_recs.push_back(rec);
-    }
-    VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], s_cb));
-    if (done_event) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, s_cb));
-    p->cb_pending[k] = true;
-    p->n++;
     return VIT_HIP_OK;
 }
 
@@ -784,10 +811,12 @@ int vit_hip_pipeline_get_timing(vit_hip_pipeline_t p, size_t capacity, float* up
     return VIT_HIP_OK;
 }
 
-int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace) {
+int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace, size_t* first_frame, size_t* frames) {
     if (!p || !d_workspace) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     if (p->n == 0) return fail(VIT_HIP_ERR_INVALID_ARG, "no batch has been submitted");
     *d_workspace = p->ws[(int)((p->n - 1) % (unsigned long long)p->n_ws)];
+    if (first_frame) *first_frame = p->last_first_frame;
+    if (frames) *frames = p->last_frames;
     return VIT_HIP_OK;
 }
 
@@ -800,6 +829,8 @@ int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedul
     s->overlap_max_frames = p->overlap_max_frames;
     s->two_updates_max_frames = p->two_updates_max_frames;
     s->workspace_bytes_each = p->ws_bytes;
+    s->sub_batch_frames = p->sub_frames;
+    s->chainback_wave_priority = (int32_t)p->cb_wave_priority;
     return VIT_HIP_OK;
 }
 

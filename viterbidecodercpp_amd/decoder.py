@@ -505,16 +505,19 @@ class DecodePipeline:
     def sync(self):
         _lib.check(_lib.load().vit_hip_pipeline_sync(self._p))
 
-    def export_last_decisions(self, frames: int, n_steps: int = None):
-        """decision rows [frames][n_steps][W] of the most recently submitted batch (after sync())"""
+    def export_last_decisions(self, frames: int = None, n_steps: int = None):
+        """decision rows of the most recently submitted (sub-)batch, after sync(): returns (first_frame, rows) where rows
+        [n][n_steps][W] belong to frames first_frame .. first_frame + n - 1 of the submitted batch (n = `frames` or the whole
+        sub-batch)"""
         dec, t = self.decoder, self.decoder.torch
         n_steps = (self.L + dec.K - 1) if n_steps is None else n_steps
-        ws = C.c_void_p()
-        _lib.check(_lib.load().vit_hip_pipeline_last_workspace(self._p, C.byref(ws)))
-        out = t.empty((frames, n_steps, dec.W), dtype=t.int64, device=dec.device)
-        _lib.check(_lib.load().vit_hip_export_decisions(dec._handle._h, ws, frames, n_steps, self.L, C.c_void_p(out.data_ptr()),
+        ws, f0, nf = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        _lib.check(_lib.load().vit_hip_pipeline_last_workspace(self._p, C.byref(ws), C.byref(f0), C.byref(nf)))
+        n = nf.value if frames is None else min(frames, nf.value)
+        out = t.empty((n, n_steps, dec.W), dtype=t.int64, device=dec.device)
+        _lib.check(_lib.load().vit_hip_export_decisions(dec._handle._h, ws, n, n_steps, self.L, C.c_void_p(out.data_ptr()),
                                                         dec._stream()))
-        return out
+        return f0.value, out
 
     def set_timing(self, enable: bool):
         _lib.check(_lib.load().vit_hip_pipeline_set_timing(self._p, 1 if enable else 0))
