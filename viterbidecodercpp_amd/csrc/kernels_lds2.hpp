@@ -280,13 +280,21 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 #ifndef VIT_L2_SCALAR_BUILD
     // lane p: E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107),
     // stored at position lds2_tab_index(p): 70 VALU per table pair, on four of the eight wavefronts
+    // `high` and `low` live in VECTOR registers for the build: the symbols are in SGPRs and a packed subtract takes only one
+    // scalar operand -- with both in SGPRs every symbol cost a v_mov first
+    // (only the compile-time-rate instantiation has the two registers to spare)
+    u32 HIGH2v = HIGH2, LOW2v = LOW2;
+    if constexpr (RT != 0) {
+        l2_opaque(HIGH2v);
+        l2_opaque(LOW2v);
+    }
     auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
         u32 e = 0, eb = 0;
         const u32 pb = (u32)lane ^ xb;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
-                const u32 d1 = l2_sub(HIGH2, y[i]), d0 = l2_sub(LOW2, y[i]);
+                const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
                 e = l2_add(e, ((lane >> i) & 1) ? a1 : a0);
                 eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
@@ -477,42 +485,52 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     // (236 bytes of scratch, ~50 reloads per block); re-forming them from the thread index in every block, as round 2 did,
     // cost 27 VALU per block.
     constexpr u32 MET_OFF = (u32)GM::tab_bytes + 32u * 4u;                 // byte offset of met[] inside lds2_smem
-    const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)tid, (u32)N);
+    const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)tid, (u32)N);     // relative to lds2_smem
     // the compile-time-rate instantiation has the registers for all four store offsets; the others carry one and form the rest
     // with a v_xor each
     constexpr int NST = RT ? 4 : 1;
     u32 st_off[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)tid ^ (u32)(q << 1));
-    auto at = [&](u32 byte_off) __attribute__((always_inline)) -> char* { return (char*)lds2_smem + byte_off; };
+    // the offsets are turned into ABSOLUTE LDS addresses once, here (the address of lds2_smem inside the workgroup's LDS is added
+    // now, not in every block), and used through explicit address-space-3 pointers; the loop-carried values themselves are made
+    // opaque in place (no copy) at each use
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const u32 lds_base = (u32)(uintptr_t)(lds_char_t*)lds2_smem;
+    u32 ld_addr = lds_base + ld_off;
+#pragma unroll
+    for (int q = 0; q < NST; ++q) st_off[q] += lds_base;
+    auto at = [&](u32 lds_addr) __attribute__((always_inline)) -> lds_char_t* { return (lds_char_t*)(uintptr_t)lds_addr; };
     auto load_group = [&](u32 (&m)[16], u32 g, u32 off) __attribute__((always_inline)) {
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            if constexpr (SEP) m[r] = *(const u32*)at(off + (u32)(r * (G / 4)) * 4u);
+            if constexpr (SEP) m[r] = *(const __attribute__((address_space(3))) u32*)at(off + (u32)(r * (G / 4)) * 4u);
             else m[r] = met[lds2_sw((u32)(r * G) + g, (u32)N)];
         });
     };
     auto load_metrics = [&]() __attribute__((always_inline)) {
-        u32 o = ld_off, t = (u32)tid;
-        l2_opaque(o);
-        l2_opaque(t);
-        load_group(mA, t, o);
-        if constexpr (GPT == 2) load_group(mB, t + (u32)T, o + (u32)T);      // lds2_sw(g + T) = lds2_sw(g) + T / 4 dwords
+        u32 t = (u32)tid;
+        l2_opaque(ld_addr);
+        if constexpr (!SEP) l2_opaque(t);
+        load_group(mA, t, ld_addr);
+        if constexpr (GPT == 2) load_group(mB, t + (u32)T, ld_addr + (u32)T);      // lds2_sw(g + T) = lds2_sw(g) + T / 4 dwords
     };
     auto store_metrics = [&]() __attribute__((always_inline)) {                 // after stage 3: register r holds state 16 g + r
         l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
+            typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) u32x4_t lds_uint4_t;
             u32 o;
             if constexpr (NST == 4) {
+                l2_opaque(st_off[q]);
                 o = st_off[q];
-                l2_opaque(o);
             } else {
-                u32 o0 = st_off[0];
-                l2_opaque(o0);
-                o = ((o0 - MET_OFF) ^ (u32)(q << 5)) + MET_OFF + 4u * (u32)(q * (N / 4));   // 16 (tid ^ 2q) = 16 tid ^ 32 q
+                if constexpr (q == 0) l2_opaque(st_off[0]);
+                // 16 (tid ^ 2q) = 16 tid ^ 32 q, on the tid part only: the constant parts (and the LDS base) are taken off first
+                o = ((st_off[0] - MET_OFF - lds_base) ^ (u32)(q << 5)) + MET_OFF + lds_base + 4u * (u32)(q * (N / 4));
             }
-            *(uint4*)at(o) = make_uint4(mA[4 * q], mA[4 * q + 1], mA[4 * q + 2], mA[4 * q + 3]);
-            if constexpr (GPT == 2) *(uint4*)at(o + 16u * (u32)T) = make_uint4(mB[4 * q], mB[4 * q + 1], mB[4 * q + 2], mB[4 * q + 3]);
+            *(lds_uint4_t*)at(o) = u32x4_t{mA[4 * q], mA[4 * q + 1], mA[4 * q + 2], mA[4 * q + 3]};
+            if constexpr (GPT == 2) *(lds_uint4_t*)at(o + 16u * (u32)T) = u32x4_t{mB[4 * q], mB[4 * q + 1], mB[4 * q + 2], mB[4 * q + 3]};
         });
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
@@ -632,7 +650,11 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     while (t0 < t_end) {
         const u32 left = t_end - t0;
         const int nst = left < (u32)BLK ? (int)left : BLK;
-        const int c_first = t0 < t_begin ? (int)(t_begin - t0) : 0;   // > 0 only in the entry block of a resumed call
+        // > 0 only in the entry block of a resumed call.  Written so that it stays on the scalar unit: t0 >= t_begin & ~3, hence
+        // t_begin - t0 is 1..3 there and wraps to a huge value everywhere else (as `t0 < t_begin ? ... : 0` hipcc computed it
+        // with a saturating VECTOR subtract and a v_readfirstlane, four VALU per block)
+        const u32 c_gap = t_begin - t0;
+        const int c_first = c_gap < (u32)BLK ? (int)c_gap : 0;
         if (nst < BLK || c_first > 0 || careful != 0) careful = slow_block(t0, set, c_first, nst);
         else careful = fast_block(set, t0, arrivals_wanted);
         // the next block reads the other table set: one base offset flips; the packed offsets are made opaque once per block (no
