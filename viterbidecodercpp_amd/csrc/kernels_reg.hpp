@@ -758,7 +758,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     } else {
                         any = __builtin_amdgcn_ballot_w64(pk_max_s(m[0], TLANE) != TCMP) != 0;
                     }
-                    if (any) {
+                    if (__builtin_expect(any, 0)) {   // rare: the body goes out of line, the hot path falls through
                         const u32 maskq = (SP::LANE_BITS == 0 || lane < 16) ? BIAS2 : 0u;              // formed here, not carried through the hot path
                         const u32 need2 = (pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq;   // sign bits: frame A / frame B
                         const u32 nq = SP::LANE_BITS ? (u32)__shfl((int)need2, (int)g) : need2;
