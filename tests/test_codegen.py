@@ -65,6 +65,17 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
         # two update waves (2048 tiles on 1024 SIMDs) + one chainback wave must fit a SIMD's 512 registers
         assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         assert 2 * alloc(usage[k]) + alloc(usage[cb[0]]) <= 512, (k, usage[k], usage[cb[0]])
+    # the update kernel's hot path falls through: the (rare) renormalisation bodies sit out of line behind not-taken
+    # s_cbranch_vccnz, one per unrolled trellis step; a taken branch per step cost 1.4 - 1.9 % and made the speed depend on where
+    # the linker put the kernel
+    for sym in (r"_ZN3vit17reg_update_kernelINS_7RegSpecILi7ELi2ELj109ELj79ELj0ELj0ELi2EEELi0EEEvNS_13RegUpdateArgsE",):
+        ulines, uloops = _inner_loops(_kernel_body(asm, sym))
+        ua, ub = max(uloops, key=lambda ab: ab[1] - ab[0])
+        labels = {m.group(1): n for n, l in enumerate(ulines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        fwd_in_loop = [l for n, l in enumerate(ulines[ua:ub], ua)
+                       for m in [re.search(r"s_cbranch_vccz\s+(\.LBB\d+_\d+)", l)] if m and n < labels.get(m.group(1), -1) <= ub]
+        assert not fwd_in_loop, fwd_in_loop[:3]
+        assert sum("s_cbranch_vccnz" in l for l in ulines[ua:ub]) >= 24
     # the chainback ring: the innermost loop that refills rows must wait with counted vmcnt, never vmcnt(0), and hold no store
     lines, loops = _inner_loops(_kernel_body(asm, r"_ZN3vit20reg_chainback_kernel\S*"))
     ring = [(a, b) for a, b in loops if sum("global_load_dwordx4" in l for l in lines[a:b]) >= 16]
