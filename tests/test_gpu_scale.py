@@ -14,6 +14,19 @@ from tests.helpers import make_table_config, oracle_cfg
 pytestmark = pytest.mark.gpu
 
 
+def _host_threads():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 logical CPUs
+    and grants 16)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _need_hbm(torch, nbytes, what):
     free, total = torch.cuda.mem_get_info()
     if free < nbytes:
@@ -50,7 +63,7 @@ def _every_frame_exact(oracle, dec, code, decode_type, pc, sym, out, met, rs, fr
     import torch
 
     S, W = L + code.K - 1, dec.W
-    threads = len(os.sched_getaffinity(0))
+    threads = _host_threads()
     want_out, want_met, want_rs, want_hash = oracle.decode_frames(
         code.K, code.R, code.G, oracle_cfg(decode_type, code.R), sym.cpu().numpy(), L, threads=threads, want_metrics=True,
         want_hash=True)
@@ -90,7 +103,7 @@ def _slabs_exact_by_digest(oracle, dec, code, decode_type, pc, sym, out, met, rs
     n_tiles = (frames + tile - 1) // tile
     slabs = sorted(set(int(x) for x in np.linspace(0, n_tiles - 1, n_slabs).round()))
     ids = np.asarray([f for sl in slabs for f in range(sl * tile, min((sl + 1) * tile, frames))])
-    threads = len(os.sched_getaffinity(0))
+    threads = _host_threads()
     d_ids = torch.from_numpy(ids).to(sym.device)
     want_out, want_met, want_rs, want_hash = oracle.decode_frames(
         code.K, code.R, code.G, oracle_cfg(decode_type, code.R), sym[d_ids].cpu().numpy(), L, threads=threads,
@@ -172,8 +185,10 @@ def test_cassini_k15_full_size(oracle):
     ber = int(dec.count_bit_errors(out, tx).item()) / float(frames * L)
     assert 1e-4 < ber < 0.1, ber              # ~1e-2 at 1 dB
     _oracle_subset(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L, n_pick=4, seed=3)
-    # ... and 16 whole frames per host thread through the threaded oracle (256 of the 4096 frames on the box's 16 cores, about
-    # a minute of wall clock), compared by digest over all 2.1 M decision words of each
+    # ... and 16 whole frames per usable host CPU through the threaded oracle (256 of the 4096 frames on the box's 16-CPU quota,
+    # 12 s of wall clock), compared by digest over all 2.1 M decision words of each; VIT_TEST_K15_ALL=1 checks all 4096 (three
+    # minutes; the first two full-suite runs of round 3 did, by accident of counting 256 logical CPUs: all equal)
     n = _slabs_exact_by_digest(oracle, dec, code, "SOFT16", pc, sym, out, met, rs, frames, L,
-                               n_slabs=8 * len(os.sched_getaffinity(0)), budget_note="K15 full size, noisy batch")
+                               n_slabs=(frames + 1) // 2 if os.environ.get("VIT_TEST_K15_ALL") else 8 * _host_threads(),
+                               budget_note="K15 full size, noisy batch")
     assert n >= 16
