@@ -171,7 +171,7 @@ __global__ void lds_update_kernel(LdsUpdateArgs a) {
         }
         __syncthreads();
 
-        if (met_new[0] >= a.cfg.threshold) {  // scalar.h:48 -- state 0 only; block-uniform
+        if (__builtin_expect(met_new[0] >= a.cfg.threshold, 0)) {  // scalar.h:48 -- state 0 only; block-uniform; rare: out of line
             uint16_t mn = 0xFFFF;             // renormalise, scalar.h:139-153
             if (wave_has_work)
                 for (int q = 0; q < ch; ++q) {
