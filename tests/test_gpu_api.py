@@ -161,6 +161,27 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     check_batch_against_oracle(oracle, code, decode_type, 33, 104, 2.0, seed=K + R, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
 
 
+@pytest.mark.parametrize("coop", ["0", "1"])
+@pytest.mark.parametrize("K,R,G,decode_type", [
+    (9, 2, (0o753, 0o561), "SOFT16"),        # CDMA IS-95A, ahead-of-time instantiation
+    (9, 4, (0o765, 0o671, 0o513, 0o473), "HARD8"),
+    (9, 3, (0o557, 0o663, 0o711), "SOFT8"),  # run-time instantiation
+])
+def test_k9_chainback_bodies(oracle, monkeypatch, K, R, G, decode_type, coop):
+    """K = 9 has two chainback kernels -- rows streamed through an LDS ring (beside an update kernel, large batches) and the
+    cooperative one (small batches alone): each is forced here at sizes the library would give to the other, with trace lengths
+    that leave ragged ends above and below the 32-step iterations, frame counts that are no multiple of a wave's 128, and
+    per-frame end states."""
+    monkeypatch.setenv("VIT_HIP_CHAINBACK_COOP", coop)
+    code = Code(f"K9R{R}", K, R, tuple(G))
+    rng = np.random.default_rng(R)
+    for F, L in ((130, 1000), (70, 384), (33, 104), (257, 40), (1, 24)):
+        ss = rng.integers(0, code.num_states, F).astype(np.int32)
+        es = rng.integers(0, code.num_states, F).astype(np.int32)
+        check_batch_against_oracle(oracle, code, decode_type, F, L, 2.0, seed=F + L, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
+    check_batch_against_oracle(oracle, code, decode_type, 200, 2048, 1.0, seed=9, plan=_lib.PLAN_REG)
+
+
 def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tmp_path):
     lib = _lib.load()
     monkeypatch.setenv("VIT_HIP_HIPCC", "/nonexistent/hipcc")
@@ -208,7 +229,8 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
     (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
     (7, "SOFT16", 24, 256, (2, 1, 0)),       # K = 15 (PLAN_LDS2): back to back
-    (5, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9: two update waves fill a SIMD's registers, so the batch goes in sub-batches of 32768
+    (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
+    (6, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9, R = 4: one update wave takes 360 registers, so the batch goes in sub-batches of 32768
 ])
 def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want):
     """vit_hip_pipeline_*: whatever schedule the library picks (two updates in flight, chainback beside the next update, or
@@ -232,7 +254,7 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
         assert (sch.workspaces, sch.update_streams, sch.chainback_overlapped) == want
     sub = int(sch.sub_batch_frames)
     if want is not None:
-        assert sub == (32768 if code_id == 5 else F) and sch.chainback_wave_priority == (1 if sch.update_streams == 2 else 0)
+        assert sub == (32768 if code_id == 6 else F) and sch.chainback_wave_priority == (1 if sch.update_streams == 2 else 0)
     assert sch.workspace_bytes_each == dec.workspace_bytes(min(F, sub), L)
     assert lib.vit_hip_pipeline_set_timing(pipe, 1) == _lib.OK
     batches, outs = [], []

@@ -957,6 +957,131 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     while (t >= SB) slow_step(t--);
 }
 
+// ---- lane-local chainback for the 64-register codes (K = 9): one lane per frame PAIR, the rows stream through LDS ----
+// A step's row of a tile (64 lanes x 16 B) holds 256 decision bits for each of its 32 frames and the chase needs ONE of them.
+// In the cooperative body above every one of the four q-lanes of a pair repeats the whole chase (34 vector instructions per
+// step for 32 frames) and a ds_bpermute picks the owner's bit: a tenth of the update kernel's instruction count, which is what
+// the two kernels compete for when they run side by side.  Here the rows never touch a register: the wave streams the rows of
+// FOUR tiles into an LDS ring with direct-to-LDS loads (global_load_lds_dwordx4, the row's 1 KiB in its own order: a ring that
+// gathered the four q-pieces of a pair side by side -- 64 scattered 16-byte requests per row instead of 8 full lines -- slowed
+// the update kernel beside it by 13 %), and each lane reads the one BYTE that holds its survivor's bit: 8 vector instructions
+// and one ds_read_u8 per frame and step, for 128 frames per wave.  The
+// kernel needs next to no registers (it is capped at 32: two 240-register update waves and one of these share a SIMD) and
+// its issue slots are a hundredth of the update's.
+template <class SP>
+VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
+    static_assert(SP::LANE_BITS == 2 && SP::NREG == 64 && SP::DW == 4 && SP::SPS == 1 && SP::SB == 8, "K = 9 layout");
+    constexpr int SB = 8;                                      // ViterbiTracebackBuffer::get_layout (core.h:129-149): K = 9 keeps
+                                                               // 8 state bits, no shift: byte j/8 = the register after bit j
+    // ring depth in trellis steps (divides 32).  Beside an update kernel 4, 8 and 16 move the same bytes per second (the chase
+    // waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keeps update waves off the CU (12.6 -> 14.1 ms per
+    // K = 9 batch); alone on the device a small batch runs 1.67 / 1.20 / 0.96 ms (8192 frames x 8192 bits)
+    constexpr int D = 8;
+    constexpr int ITER = 32;                                   // steps per iteration = one output dword per frame
+    constexpr int KI = 16;                                     // iterations between flushes: 64 output bytes per frame
+    __shared__ uint4 ring[D * 4 * 64];                         // [slot][tile of the wave][LDS position]
+    __shared__ u32 obuf[2 * KI * 64];                          // [frame half][iteration][lane]
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void glb_void_t;
+    typedef u32 u32_unaligned __attribute__((aligned(1)));
+
+    const int lane = threadIdx.x & 63;
+    const u32 n_tiles = (a.frames + 31u) >> 5;
+    const u32 jt = (u32)lane >> 4, g = (u32)lane & 15u;
+    // surplus tiles / frames redo the last one: the update kernel filled their slots with that frame's decisions, so the
+    // stores are identical
+    const u32 tl_raw = blockIdx.x * 4u + jt;
+    const u32 tl = tl_raw < n_tiles ? tl_raw : n_tiles - 1;
+    const u32 fA = tl * 32u + g < a.frames ? tl * 32u + g : a.frames - 1;
+    const u32 fB = tl * 32u + g + 16u < a.frames ? tl * 32u + g + 16u : a.frames - 1;
+    const size_t out_stride = ((size_t)a.L + 7) / 8;
+    uint8_t* outA = a.out + (size_t)fA * out_stride;
+    uint8_t* outB = a.out + (size_t)fB * out_stride;
+    const uint8_t* my_rows = (const uint8_t*)(a.ws + (size_t)tl * a.ws_tile_stride);   // row of step t at + 1024 t
+    const u32 src_off = (u32)lane * 16u;                                                // the row piece this lane moves: LDS keeps the row's order
+    const u32 pair_base = jt * 1024u + g * 16u;                                         // the pair's q = 0 piece inside a ring slot
+
+    // the shift register of the chase, 32 bits wide: state = top byte, and after 32 steps the four bytes are output bytes
+    u32 RA = (a.end_state ? (a.end_state[fA] & 0xFFu) : 0u) << 24;
+    u32 RB = (a.end_state ? (a.end_state[fB] & 0xFFu) : 0u) << 24;
+
+    // the slot of `state` after step t is x = rotr8(state, (t + 1) % 8); its decision bit is bit x & 7 of byte
+    // 2 ((x >> 3) & 7) + half of the pair's q-piece x >> 6 (dword (x >> 4) & 3, SP::dec_bit inside it)
+    auto pick = [&](u32& R, u32 byte, u32 b) __attribute__((always_inline)) {
+        const u32 bit = __builtin_amdgcn_ubfe(byte, b, 1);
+        R = (R >> 1) | (bit << 31);
+    };
+    auto slow_step = [&](int t) __attribute__((always_inline)) {
+        const u32 ph1 = (u32)(t + 1) & 7u;
+        const u32 sA = RA >> 24, sB = RB >> 24;
+        const u32 xA = ((sA >> ph1) | (sA << (8 - ph1))) & 0xFFu, xB = ((sB >> ph1) | (sB << (8 - ph1))) & 0xFFu;
+        const uint8_t* row = my_rows + (size_t)t * 1024u + g * 16u;
+        const u32 bA = row[(xA >> 6) * 256u + ((xA >> 3) & 7u) * 2u], bB = row[(xB >> 6) * 256u + ((xB >> 3) & 7u) * 2u + 1u];
+        pick(RA, bA, xA & 7u);
+        pick(RB, bB, xB & 7u);
+        const int j = t - SB;
+        if ((j & 7) == 0) { outA[j >> 3] = (uint8_t)(RA >> 24); outB[j >> 3] = (uint8_t)(RB >> 24); }
+    };
+
+    int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
+    while (t >= SB && (t & (ITER - 1)) != 7) slow_step(t--);    // down to t = 7 mod 32: phases and output dwords line up
+    if (t - (ITER - 1) >= SB) {
+        // uniform row bases of the wave's four tiles
+        const uint8_t* tb[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const u32 tr = blockIdx.x * 4u + (u32)jj;
+            tb[jj] = (const uint8_t*)(a.ws + (size_t)(tr < n_tiles ? tr : n_tiles - 1) * a.ws_tile_stride);
+        }
+        auto fill = [&](int slot, int step) __attribute__((always_inline)) {
+            // scalar tile base + ONE 32-bit per-lane offset for the four loads (a tile's rows stay below 4 GiB)
+            const u32 vo = src_off + (u32)(step < 0 ? 0 : step) * 1024u;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(ring + (slot * 4 + jj) * 64), 16, 0, 0);
+        };
+#pragma unroll
+        for (int k = 0; k < D; ++k) fill(k, t - k);
+        const uint8_t* ring_b = (const uint8_t*)ring;
+        while (t - (ITER - 1) >= SB) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): retire the previous flush (and the ring)
+            const int t0 = t;
+            int it = 0;
+            for (; it < KI && t - (ITER - 1) >= SB; ++it, t -= ITER) {
+#pragma unroll
+                for (int pk = 0; pk < ITER; ++pk) {
+                    const int k = pk % D;                        // ring slot
+                    const u32 ph1 = (u32)((8 - pk % 8) % 8);     // step t - pk, t = 7 mod 8: (t - pk + 1) % 8
+                    // the slot's four loads are the oldest of the 4 D in flight
+                    constexpr int NV = 4 * (D - 1);
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | (NV & 15) | ((NV >> 4) << 14));   // vmcnt(4 D - 4)
+                    const u32 dA = __builtin_amdgcn_perm(RA, RA, 0x0c0c0303u), dB = __builtin_amdgcn_perm(RB, RB, 0x0c0c0303u);   // state | state << 8
+                    const u32 aA = pair_base + 256u * __builtin_amdgcn_ubfe(dA, ph1 + 6, 2) + 2u * __builtin_amdgcn_ubfe(dA, ph1 + 3, 3);
+                    const u32 aB = pair_base + 256u * __builtin_amdgcn_ubfe(dB, ph1 + 6, 2) + 2u * __builtin_amdgcn_ubfe(dB, ph1 + 3, 3);
+                    const u32 wA = ring_b[k * 4096 + aA], wB = ring_b[k * 4096 + 1 + aB];
+                    pick(RA, wA, __builtin_amdgcn_ubfe(dA, ph1, 3));
+                    pick(RB, wB, __builtin_amdgcn_ubfe(dB, ph1, 3));
+                    // the refill overwrites what the two reads above fetched: they have returned (their bits are in RA / RB)
+                    asm volatile("" : "+v"(RA), "+v"(RB) : : "memory");
+                    fill(k, t - pk - D);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // bytes j/8 of the 32 steps, first decoded bit of each byte on top: RA's top byte is the LOWEST byte index
+                obuf[it * 64 + lane] = __builtin_amdgcn_perm(RA, RA, 0x00010203u);
+                obuf[(KI + it) * 64 + lane] = __builtin_amdgcn_perm(RB, RB, 0x00010203u);
+            }
+            // iteration i covered steps t0 - 32 i - 31 ... t0 - 32 i: bytes (t0 - 32 i - 31 - SB) / 8 ... + 3
+            for (int i = 0; i < it; ++i) {
+                const u32 jb = (u32)(t0 - ITER * i - (ITER - 1) - SB) >> 3;
+                *(u32_unaligned*)(outA + jb) = obuf[i * 64 + lane];
+                *(u32_unaligned*)(outB + jb) = obuf[(KI + i) * 64 + lane];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring's last (surplus) loads land before LDS is released
+    }
+    while (t >= SB) slow_step(t--);
+}
+
 // ---- lane-local chainback for the 16-register codes (K = 7): one lane per frame PAIR, 64 pairs (four tiles) per wave ----
 // Nothing on the dependent bit-chase leaves the lane: the four q-rows of a step (16 B each, 4 steps per row) are all loaded
 // by the pair's lane, and every loaded byte is used (byte 0/2 of a dword = frame A, byte 1/3 = frame B; a lane per FRAME
@@ -1216,8 +1341,21 @@ VIT_DEV void reg_export_body(const RegExportArgs& a) {
 // branch metrics) and keeps one wave per SIMD.
 template <class SP>
 constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 : 2; }
+// K = 9, R = 2: capped at 240 registers (the attribute counts in halves of the unified file: 120).  hipcc's schedule for 256
+// holds no more live values than fit 240 (no scratch either way), the capped kernel runs 2.7 % FASTER (10.99 vs 11.29 ms,
+// 65536 x 8192) and two of its waves leave 32 registers per SIMD: the K = 9 chainback's allocation (reg_chainback64_body)
+// (the attribute takes a literal, not a template-dependent value: the translation unit of the code sets it -- reg_inst.hip
+// with -DVIT_REG_ID=3, reg_jit.hpp for a run-time compiled K = 9, R = 2 code)
+#if !defined(VIT_REG_UPDATE_VGPR_CAP) && defined(VIT_REG_ID)
+#if VIT_REG_ID == 3
+#define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))
+#endif
+#endif
+#ifndef VIT_REG_UPDATE_VGPR_CAP
+#define VIT_REG_UPDATE_VGPR_CAP
+#endif
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, false>(a); }
+__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, false>(a); }
 template <class SP, int SHIFT>
 __global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_resume_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, true>(a); }
 
@@ -1226,17 +1364,29 @@ template <class SP>
 VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
     if constexpr (SP::LANE_BITS == 0) reg_chainback0_body<SP>(a);
     else if constexpr (SP::NREG == 16) reg_chainback16_body<SP>(a);
+    else if constexpr (SP::NREG == 64) reg_chainback64_body<SP>(a);
     else reg_chainback_coop_body<SP>(a);
 }
 template <class SP>
-constexpr unsigned reg_chainback_frames_per_block() { return SP::NREG == 16 && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
+constexpr unsigned reg_chainback_frames_per_block() { return (SP::NREG == 16 || SP::NREG == 64) && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
+// (the K = 9 body's LDS ring -- 40 KiB per one-wave workgroup -- allows four of them per CU)
 template <class SP>
-__global__ void __launch_bounds__(64, 2) reg_chainback_kernel(RegChainbackArgs a) {
+constexpr int reg_chainback_min_waves() { return SP::NREG == 64 ? 1 : 2; }
+template <class SP>
+__global__ void __launch_bounds__(64, reg_chainback_min_waves<SP>()) reg_chainback_kernel(RegChainbackArgs a) {
     // beside TWO update kernels (the small-batch pipeline schedule) the bit chase would otherwise get the issue slots both leave
     // over and become the pipeline's bottleneck: there it runs at the higher wave priority
     if (a.wave_priority) __builtin_amdgcn_s_setprio(3);
     reg_chainback_body<SP>(a);
 }
+// K = 9 alone on the device with a batch too small to be bandwidth bound: the cooperative body (one wave per 32 frames: four times
+// the waves, no direct-to-LDS issue cost on the chase's path -- 8192 frames x 8192 bits 0.79 ms against 1.20 ms; level at 65536)
+template <class SP>
+__global__ void __launch_bounds__(64, 2) reg_chainback_coop_kernel(RegChainbackArgs a) {
+    if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);
+}
+// frames up to which reg_chainback() prefers it when the kernel runs alone
+constexpr size_t REG_CHAINBACK64_COOP_MAX_FRAMES = 32768;
 template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 
@@ -1256,6 +1406,7 @@ struct RegJitModule {
     hipFunction_t update[2] = {nullptr, nullptr};   // [0] 16-bit, [1] 8-bit metrics/symbols
     hipFunction_t resume[2] = {nullptr, nullptr};
     hipFunction_t chainback = nullptr, export_ = nullptr;
+    hipFunction_t chainback_coop = nullptr;         // K = 9 only: reg_chainback_coop_kernel, 32 frames per block
     unsigned chainback_frames_per_block = 32;
 };
 
@@ -1313,7 +1464,7 @@ template <> struct RegSpecOf<5> { using type = Spec_K3R2; };
 template <> struct RegSpecOf<6> { using type = Spec_K5R2; };
 
 template <int ID> int reg_launch_update(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st);
-template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st);
+template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st, bool coop);
 template <int ID> int reg_launch_export(const RegExportArgs& a, unsigned blocks, hipStream_t st);
 // vector registers (arch + accumulation) one wave of the update / chainback kernel holds: what decides which kernels can share a SIMD
 template <int ID> int reg_query_vgprs(int shift, int* update_regs, int* chainback_regs);
@@ -1330,10 +1481,11 @@ template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a,
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st) {
+template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st, bool coop) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
     constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
-    hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), 0, st, a);
+    if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
@@ -1360,13 +1512,13 @@ template <> int reg_launch_update<3>(int, const RegUpdateArgs&, unsigned, hipStr
 template <> int reg_launch_update<4>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_update<5>(int, const RegUpdateArgs&, unsigned, hipStream_t);
 template <> int reg_launch_update<6>(int, const RegUpdateArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<0>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<1>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<2>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<3>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<4>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<5>(const RegChainbackArgs&, unsigned, hipStream_t);
-template <> int reg_launch_chainback<6>(const RegChainbackArgs&, unsigned, hipStream_t);
+template <> int reg_launch_chainback<0>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<1>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<2>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<3>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<4>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<5>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
+template <> int reg_launch_chainback<6>(const RegChainbackArgs&, unsigned, hipStream_t, bool);
 template <> int reg_launch_export<0>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<1>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<2>(const RegExportArgs&, unsigned, hipStream_t);
@@ -1453,7 +1605,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
 }
 
 inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
-                         hipStream_t st, unsigned wave_priority = 0) {
+                         hipStream_t st, unsigned wave_priority = 0, bool beside_update = false) {
     if (frames == 0 || L == 0) return 0;
     RegChainbackArgs a{};
     a.ws = (const uint4*)d_ws;
@@ -1464,18 +1616,23 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.L = (u32)L;
     a.wave_priority = wave_priority;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
+    // K = 9: the LDS-streaming body beside an update kernel (it fits the registers two update waves leave and costs them no
+    // issue slots) and for batches that are bandwidth bound anyway, the cooperative body for a small batch on its own
+    bool coop = rc.K == 9 && !beside_update && frames <= REG_CHAINBACK64_COOP_MAX_FRAMES;
+    if (const char* e = getenv("VIT_HIP_CHAINBACK_COOP")) coop = rc.K == 9 && *e == '1';   // tests: either body at any size
     if (rc.jit) {
+        if (coop && rc.jit->chainback_coop) return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), tiles, 64, st);
         const unsigned fpb = rc.jit->chainback_frames_per_block;
         return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st);
     }
     switch (rc.id) {
-        case 0: return reg_launch_chainback<0>(a, tiles, st);
-        case 1: return reg_launch_chainback<1>(a, tiles, st);
-        case 2: return reg_launch_chainback<2>(a, tiles, st);
-        case 3: return reg_launch_chainback<3>(a, tiles, st);
-        case 4: return reg_launch_chainback<4>(a, tiles, st);
-        case 5: return reg_launch_chainback<5>(a, tiles, st);
-        case 6: return reg_launch_chainback<6>(a, tiles, st);
+        case 0: return reg_launch_chainback<0>(a, tiles, st, coop);
+        case 1: return reg_launch_chainback<1>(a, tiles, st, coop);
+        case 2: return reg_launch_chainback<2>(a, tiles, st, coop);
+        case 3: return reg_launch_chainback<3>(a, tiles, st, coop);
+        case 4: return reg_launch_chainback<4>(a, tiles, st, coop);
+        case 5: return reg_launch_chainback<5>(a, tiles, st, coop);
+        case 6: return reg_launch_chainback<6>(a, tiles, st, coop);
         default: return -1;
     }
 }
