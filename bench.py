@@ -383,6 +383,19 @@ def main():
 
         def last_decisions(n):            # decision rows of the LAST timed launch, straight from the pipeline's workspace
             return pipe.export_last_decisions(n)
+
+        def clock_under_load():
+            # UNTIMED extra batches with the clock probe launched in their middle: the shader clock while the decode kernels
+            # (and whatever memory traffic they overlap with) run -- lower than the probe's own before / after figures where a
+            # memory-heavy chainback shares the card with the update (K = 9: ~2.25 GHz against 2.39 GHz beside the update alone)
+            step_ms = float(np.median(step_times))
+            n = int(np.ceil(30.0 / max(step_ms, 0.1))) + 3
+            for _ in range(n):
+                pipe.submit(sym, out)
+            time.sleep(1.5 * step_ms / 1e3)
+            c = shader_clock()
+            pipe.sync()
+            return c
     else:
         # ---- A/B: the same schedule from Python.  Decision workspaces and HIP streams as vit_hip_pipeline_create picks them:
         # update() is VALU-issue bound, chainback() is a latency/HBM-bound bit chase, so step i's chainback runs beside step
@@ -446,6 +459,7 @@ def main():
         step_times = np.diff(np.concatenate([[0.0], t_done]))
 
         F_launch = F
+        clock_under_load = None
 
         def last_decisions(n):
             return 0, dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
@@ -470,6 +484,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    clock_load = clock_under_load() if clock_under_load is not None else (None, None)
     total_bits = float(F) * L * world * args.steps
     value = total_bits / elapsed / 1e6
     step_ms = elapsed / args.steps * 1e3
@@ -510,9 +525,12 @@ def main():
         "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
         # the clock the SIMDs sustained under a packed-integer load right before / after the timed region (s_memtime against
         # s_memrealtime around ~2 ms of v_pk_add_u16 on every SIMD: vit_hip_shader_clock_mhz), and the nominal maximum
+        # "under_load": the same probe launched WHILE untimed extra batches run on the pipeline's streams (its own instruction
+        # rate, well above the idle 3.2 cycles, shows that it shared the SIMDs with them)
         "clock_mhz": {"before": clock_before[0], "after": clock_after[0], "before_warmup": clock_cold[0],
-                      "nominal_max_spec": CLOCK_GHZ * 1e3,
-                      "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]]},
+                      "under_load": clock_load[0], "nominal_max_spec": CLOCK_GHZ * 1e3,
+                      "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]],
+                      "cycles_per_pk_instr_probe_under_load": clock_load[1]},
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes_launch, "frames_per_launch": F_launch,
