@@ -333,10 +333,10 @@ def main():
     lib = _lib.load()
     import ctypes as C
 
-    def shader_clock():
+    def shader_clock(light=False):
         mhz, cyc = C.c_double(0), C.c_double(0)
-        _lib.check(lib.vit_hip_shader_clock_mhz(local_rank, C.byref(mhz), C.byref(cyc)))
-        return float(mhz.value), float(cyc.value)
+        _lib.check(lib.vit_hip_shader_clock_mhz(local_rank, C.byref(mhz), None if light else C.byref(cyc)))
+        return float(mhz.value), (None if light else float(cyc.value))
 
     simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
     dec._handle.refresh()
@@ -393,9 +393,11 @@ def main():
             for _ in range(n):
                 pipe.submit(sym, out)
             time.sleep(1.5 * step_ms / 1e3)
-            c = shader_clock()
+            t_probe = time.perf_counter()
+            c = shader_clock(light=True)                       # one wave per CU: does not load the SIMDs it measures
+            t_probe = time.perf_counter() - t_probe
             pipe.sync()
-            return c
+            return c[0], {"probe_ms": t_probe * 1e3, "batches_in_flight_during_probe": n}
     else:
         # ---- A/B: the same schedule from Python.  Decision workspaces and HIP streams as vit_hip_pipeline_create picks them:
         # update() is VALU-issue bound, chainback() is a latency/HBM-bound bit chase, so step i's chainback runs beside step
@@ -525,12 +527,12 @@ def main():
         "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
         # the clock the SIMDs sustained under a packed-integer load right before / after the timed region (s_memtime against
         # s_memrealtime around ~2 ms of v_pk_add_u16 on every SIMD: vit_hip_shader_clock_mhz), and the nominal maximum
-        # "under_load": the same probe launched WHILE untimed extra batches run on the pipeline's streams (its own instruction
-        # rate, well above the idle 3.2 cycles, shows that it shared the SIMDs with them)
+        # "under_load": a ONE-wave-per-CU probe launched WHILE untimed extra batches run on the pipeline's streams (the
+        # batches submitted outlast it: 30 ms of work and more against a probe of a millisecond or two)
         "clock_mhz": {"before": clock_before[0], "after": clock_after[0], "before_warmup": clock_cold[0],
                       "under_load": clock_load[0], "nominal_max_spec": CLOCK_GHZ * 1e3,
                       "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]],
-                      "cycles_per_pk_instr_probe_under_load": clock_load[1]},
+                      "under_load_probe": clock_load[1]},
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes_launch, "frames_per_launch": F_launch,

@@ -259,8 +259,10 @@ int vit_hip_count_bit_errors(vit_hip_handle h, const uint8_t* d_a, const uint8_t
 /* The clock the SIMDs sustain under the update kernels' instruction class, measured on the device: every SIMD runs four waves
  * of independent v_pk_add_u16 for about 2 ms between readings of s_memtime (shader clocks) and s_memrealtime (constant
  * reference clock); *mhz_out = their median ratio x the reference rate.  *cycles_per_pk_instr_out (may be NULL) = shader
- * clocks one SIMD needed per wave64 packed instruction in that loop.  Synchronous; measurement harness (bench.py quotes its
- * VALU ceiling at this clock, not at a nominal one). */
+ * clocks one SIMD needed per wave64 packed instruction in that loop.  With cycles_per_pk_instr_out == NULL the probe is ONE
+ * wave per CU: light enough to read the clock WHILE other kernels run (launched on the null stream; the decode pipeline's
+ * streams are non-blocking) without adding a chip full of vector work to their power draw.  Synchronous; measurement harness
+ * (bench.py quotes its VALU ceiling at this clock, not at a nominal one). */
 int vit_hip_shader_clock_mhz(int device, double* mhz_out, double* cycles_per_pk_instr_out);
 
 /* ---- host-pointer compatibility route (one decoder object, streaming) ------------------------------------------ */

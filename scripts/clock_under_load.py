@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Shader clock WHILE the decode kernels run: vit_hip_shader_clock_mhz (s_memtime over s_memrealtime inside its own small
-kernel on the null stream) is called with batches in flight on the pipeline's streams.  usage: clock_under_load.py <code> <type> <frames> <bits>"""
+"""Shader clock WHILE the decode kernels run: vit_hip_shader_clock_mhz (s_memtime over s_memrealtime inside its own one-wave-
+per-CU kernel on the null stream) is called with batches in flight on the pipeline's streams; prints (MHz, probe ms).  usage: clock_under_load.py <code> <type> <frames> <bits>"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,25 +17,26 @@ out = torch.zeros((F, L // 8), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 
 def clock():
-    mhz, cyc = C.c_double(0), C.c_double(0)
-    assert lib.vit_hip_shader_clock_mhz(0, C.byref(mhz), C.byref(cyc)) == _lib.OK
-    return round(mhz.value), round(cyc.value, 3)
+    mhz = C.c_double(0)
+    t0 = time.perf_counter()
+    assert lib.vit_hip_shader_clock_mhz(0, C.byref(mhz), None) == _lib.OK       # the light probe: one wave per CU
+    return round(mhz.value), round((time.perf_counter() - t0) * 1e3, 2)
 
 for _ in range(3): clock()
 print(code.name, dt, F, L)
 print("idle            ", [clock() for _ in range(3)])
 pipe = DecodePipeline(dec, F, L)
 for rep in range(2):
-    for _ in range(8): pipe.submit(sym, out)
-    time.sleep(0.03)
-    c = [clock() for _ in range(2)]
+    for _ in range(12): pipe.submit(sym, out)
+    time.sleep(0.02)
+    c = [clock() for _ in range(3)]
     pipe.sync()
     print("pipeline busy   ", c)
 s = torch.cuda.Stream()
 for rep in range(2):
     with torch.cuda.stream(s):
-        for _ in range(8): dec.update(sym, L, want_metrics=False)
-    time.sleep(0.03)
-    c = [clock() for _ in range(2)]
+        for _ in range(12): dec.update(sym, L, want_metrics=False)
+    time.sleep(0.02)
+    c = [clock() for _ in range(3)]
     torch.cuda.synchronize()
     print("update only busy", c)

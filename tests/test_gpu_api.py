@@ -161,25 +161,28 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     check_batch_against_oracle(oracle, code, decode_type, 33, 104, 2.0, seed=K + R, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
 
 
-@pytest.mark.parametrize("coop", ["0", "1"])
+@pytest.mark.parametrize("alt", ["0", "1"])
 @pytest.mark.parametrize("K,R,G,decode_type", [
     (9, 2, (0o753, 0o561), "SOFT16"),        # CDMA IS-95A, ahead-of-time instantiation
     (9, 4, (0o765, 0o671, 0o513, 0o473), "HARD8"),
     (9, 3, (0o557, 0o663, 0o711), "SOFT8"),  # run-time instantiation
+    (7, 2, (0o155, 0o117), "SOFT16"),        # Voyager
+    (7, 2, (0o171, 0o133), "HARD8"),         # run-time instantiation
 ])
-def test_k9_chainback_bodies(oracle, monkeypatch, K, R, G, decode_type, coop):
-    """K = 9 has two chainback kernels -- rows streamed through an LDS ring (beside an update kernel, large batches) and the
-    cooperative one (small batches alone): each is forced here at sizes the library would give to the other, with trace lengths
-    that leave ragged ends above and below the 32-step iterations, frame counts that are no multiple of a wave's 128, and
-    per-frame end states."""
-    monkeypatch.setenv("VIT_HIP_CHAINBACK_COOP", coop)
-    code = Code(f"K9R{R}", K, R, tuple(G))
+def test_chainback_bodies(oracle, monkeypatch, K, R, G, decode_type, alt):
+    """K = 7 and K = 9 have two chainback kernels each -- rows streamed through an LDS ring (K = 9: beside an update kernel and
+    for large batches; K = 7: experiments only) and a register-ring / cooperative one (K = 7: always; K = 9: small batches
+    alone): each is forced here at sizes the library would give to the other, with trace lengths that leave ragged ends above
+    and below the 32-step iterations, frame counts that are no multiple of a wave's 128, and per-frame end states."""
+    monkeypatch.setenv("VIT_HIP_CHAINBACK_ALT", alt)
+    code = Code(f"K{K}R{R}", K, R, tuple(G))
     rng = np.random.default_rng(R)
-    for F, L in ((130, 1000), (70, 384), (33, 104), (257, 40), (1, 24)):
+    for F, L in ((130, 1000), (70, 384), (33, 104), (257, 40), (1, 24), (3, 8)):
         ss = rng.integers(0, code.num_states, F).astype(np.int32)
         es = rng.integers(0, code.num_states, F).astype(np.int32)
         check_batch_against_oracle(oracle, code, decode_type, F, L, 2.0, seed=F + L, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
     check_batch_against_oracle(oracle, code, decode_type, 200, 2048, 1.0, seed=9, plan=_lib.PLAN_REG)
+    check_batch_against_oracle(oracle, code, decode_type, 40, 2048 + 8 * (K + R), 1.0, seed=10, plan=_lib.PLAN_REG)
 
 
 def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tmp_path):
@@ -302,6 +305,9 @@ def test_shader_clock_measurement():
     assert _lib.load().vit_hip_shader_clock_mhz(0, C.byref(mhz), C.byref(cyc)) == _lib.OK
     assert 500.0 < mhz.value < 3000.0, mhz.value          # MI355X: 2400 MHz peak engine clock
     assert 1.0 < cyc.value < 16.0, cyc.value              # shader clocks per wave64 v_pk_add_u16 and SIMD, four waves resident
+    light = C.c_double(0)                                  # clock only: the one-wave-per-CU probe
+    assert _lib.load().vit_hip_shader_clock_mhz(0, C.byref(light), None) == _lib.OK
+    assert 500.0 < light.value < 3000.0 and abs(light.value - mhz.value) < 0.25 * mhz.value, (light.value, mhz.value)
 
 
 @pytest.mark.parametrize("K,R,G,plan,F,L", [

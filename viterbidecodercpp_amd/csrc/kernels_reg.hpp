@@ -957,29 +957,33 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     while (t >= SB) slow_step(t--);
 }
 
-// ---- lane-local chainback for the 64-register codes (K = 9): one lane per frame PAIR, the rows stream through LDS ----
-// A step's row of a tile (64 lanes x 16 B) holds 256 decision bits for each of its 32 frames and the chase needs ONE of them.
-// In the cooperative body above every one of the four q-lanes of a pair repeats the whole chase (34 vector instructions per
-// step for 32 frames) and a ds_bpermute picks the owner's bit: a tenth of the update kernel's instruction count, which is what
-// the two kernels compete for when they run side by side.  Here the rows never touch a register: the wave streams the rows of
-// FOUR tiles into an LDS ring with direct-to-LDS loads (global_load_lds_dwordx4, the row's 1 KiB in its own order: a ring that
-// gathered the four q-pieces of a pair side by side -- 64 scattered 16-byte requests per row instead of 8 full lines -- slowed
-// the update kernel beside it by 13 %), and each lane reads the one BYTE that holds its survivor's bit: 8 vector instructions
-// and one ds_read_u8 per frame and step, for 128 frames per wave.  The
-// kernel needs next to no registers (it is capped at 32: two 240-register update waves and one of these share a SIMD) and
-// its issue slots are a hundredth of the update's.
+// ---- lane-local chainback through an LDS ring (K = 7, K = 9): one lane per frame PAIR, 128 frames per wave ----
+// A step's decisions of a tile are 64 lanes x 16 B / SPS and the chase needs ONE bit per frame of them.  Here the rows never
+// touch a register: the wave streams the 1 KiB rows of FOUR tiles into an LDS ring with direct-to-LDS loads
+// (global_load_lds_dwordx4, each row in its own order; counted vmcnt waits), and each lane reads the one BYTE that holds its
+// survivor's bit.  The chase keeps the survivor's SLOT, not its state: the update's in-place layout moves no state between
+// slots, so going back one step replaces exactly one bit of the slot index (position (SB - (t+1) % SB) % SB) by the decision
+// bit -- a shift and a bit-field insert, no rotation.  9 vector instructions and one ds_read_u8 per frame and step, two dozen
+// registers: the kernel fits beside whatever the update kernels leave of a SIMD (K = 9: two 240-register waves; K = 7: three
+// 152-register ones), and its issue slots are a hundredth of theirs (K = 9, cooperative body: a tenth).
 template <class SP>
-VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
-    static_assert(SP::LANE_BITS == 2 && SP::NREG == 64 && SP::DW == 4 && SP::SPS == 1 && SP::SB == 8, "K = 9 layout");
-    constexpr int SB = 8;                                      // ViterbiTracebackBuffer::get_layout (core.h:129-149): K = 9 keeps
-                                                               // 8 state bits, no shift: byte j/8 = the register after bit j
-    // ring depth in trellis steps (divides 32).  Beside an update kernel 4, 8 and 16 move the same bytes per second (the chase
-    // waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keeps update waves off the CU (12.6 -> 14.1 ms per
-    // K = 9 batch); alone on the device a small batch runs 1.67 / 1.20 / 0.96 ms (8192 frames x 8192 bits)
-    constexpr int D = 8;
+VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
+    static_assert(SP::LANE_BITS == 2 && (SP::NREG == 16 || SP::NREG == 64) && SP::DW * SP::SPS == 4 && SP::SB <= 8, "K = 7, 9 layouts");
+    constexpr int SB = SP::SB, REG_BITS = SP::REG_BITS, DW = SP::DW, SPS = SP::SPS;
+    constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
+    constexpr int SHIFT_STATE = 8 - IGN;                       // the 8-bit register holds the state in its top SB bits ...
+    static_assert(SB - IGN == 0, "... and its low byte is the output byte (shift_tail = 0)");
     constexpr int ITER = 32;                                   // steps per iteration = one output dword per frame
+    constexpr int ROWS_IT = ITER / SPS;                        // rows an iteration retires
+    // ring depth in rows (divides ROWS_IT).  K = 9, beside an update kernel: 4, 8 and 16 rows move the same bytes per second
+    // (the chase waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keep update waves off the CU (12.6 ->
+    // 14.1 ms per batch); alone on the device a small batch runs 1.67 / 1.20 / 0.96 ms (8192 frames x 8192 bits)
+    constexpr int D = 8;
+    static_assert(ROWS_IT % D == 0, "ring slots are compile-time constants");
     constexpr int KI = 16;                                     // iterations between flushes: 64 output bytes per frame
-    __shared__ uint4 ring[D * 4 * 64];                         // [slot][tile of the wave][LDS position]
+    // the top step of every iteration: t = CT mod 32 (its last decoded bit j = t - SB is a multiple of 32)
+    constexpr int CT = (ITER - 1 + SB) % ITER;
+    __shared__ uint4 ring[D * 4 * 64];                         // [slot][tile of the wave][lane of the row]
     __shared__ u32 obuf[2 * KI * 64];                          // [frame half][iteration][lane]
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -997,34 +1001,41 @@ VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
     const size_t out_stride = ((size_t)a.L + 7) / 8;
     uint8_t* outA = a.out + (size_t)fA * out_stride;
     uint8_t* outB = a.out + (size_t)fB * out_stride;
-    const uint8_t* my_rows = (const uint8_t*)(a.ws + (size_t)tl * a.ws_tile_stride);   // row of step t at + 1024 t
-    const u32 src_off = (u32)lane * 16u;                                                // the row piece this lane moves: LDS keeps the row's order
+    const uint8_t* my_rows = (const uint8_t*)(a.ws + (size_t)tl * a.ws_tile_stride);   // row of step t at + 1024 (t / SPS)
+    const u32 src_off = (u32)lane * 16u;                                                // the row piece this lane moves
     const u32 pair_base = jt * 1024u + g * 16u;                                         // the pair's q = 0 piece inside a ring slot
 
-    // the shift register of the chase, 32 bits wide: state = top byte, and after 32 steps the four bytes are output bytes
-    u32 RA = (a.end_state ? (a.end_state[fA] & 0xFFu) : 0u) << 24;
-    u32 RB = (a.end_state ? (a.end_state[fB] & 0xFFu) : 0u) << 24;
+    int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
+    // the output shift register, 32 bits wide: after 32 steps its four bytes are output bytes (reference: the top byte of an
+    // 8-bit register that starts as end_state << shift_state) ...
+    const u32 esA = a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u, esB = a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u;
+    u32 RA = esA << (24 + SHIFT_STATE), RB = esB << (24 + SHIFT_STATE);
+    // ... and the survivor's slot after step t: rotr_SB(state, (t + 1) % SB)
+    u32 ph = (u32)(t + 1) % (u32)SB;
+    u32 xA = ((esA >> ph) | (esA << (SB - ph))) & SP::SMASK, xB = ((esB >> ph) | (esB << (SB - ph))) & SP::SMASK;
+    u32 pos = (SB - ph) % SB;                                   // the slot bit the decision of step t replaces (wave-uniform)
 
-    // the slot of `state` after step t is x = rotr8(state, (t + 1) % 8); its decision bit is bit x & 7 of byte
-    // 2 ((x >> 3) & 7) + half of the pair's q-piece x >> 6 (dword (x >> 4) & 3, SP::dec_bit inside it)
-    auto pick = [&](u32& R, u32 byte, u32 b) __attribute__((always_inline)) {
-        const u32 bit = __builtin_amdgcn_ubfe(byte, b, 1);
-        R = (R >> 1) | (bit << 31);
+    // slot x = (q << REG_BITS) | r: q-piece x >> REG_BITS of the row, and inside its 16 bytes dword sidx * DW + (r >> 4), byte
+    // 2 ((r >> 3) & 1) + half, bit r & 7 (SP::dec_bit)  =>  byte 4 DW sidx + 2 (r >> 3) + half
+    auto byte_of = [&](u32 x, u32 base) __attribute__((always_inline)) -> u32 {
+        return base + 256u * __builtin_amdgcn_ubfe(x, REG_BITS, 2) + 2u * __builtin_amdgcn_ubfe(x, 3, REG_BITS - 3);
     };
-    auto slow_step = [&](int t) __attribute__((always_inline)) {
-        const u32 ph1 = (u32)(t + 1) & 7u;
-        const u32 sA = RA >> 24, sB = RB >> 24;
-        const u32 xA = ((sA >> ph1) | (sA << (8 - ph1))) & 0xFFu, xB = ((sB >> ph1) | (sB << (8 - ph1))) & 0xFFu;
-        const uint8_t* row = my_rows + (size_t)t * 1024u + g * 16u;
-        const u32 bA = row[(xA >> 6) * 256u + ((xA >> 3) & 7u) * 2u], bB = row[(xB >> 6) * 256u + ((xB >> 3) & 7u) * 2u + 1u];
-        pick(RA, bA, xA & 7u);
-        pick(RB, bB, xB & 7u);
-        const int j = t - SB;
+    auto step_back = [&](u32& R, u32& x, u32 byte, u32 p) __attribute__((always_inline)) {
+        const u32 bit = __builtin_amdgcn_ubfe(byte, x & 7u, 1);
+        R = (R >> 1) | (bit << 31);
+        x = (x & ~(1u << p)) | (bit << p);
+    };
+    auto slow_step = [&](int tt) __attribute__((always_inline)) {
+        const uint8_t* row = my_rows + (size_t)(tt / SPS) * 1024u + (u32)(tt % SPS) * (4u * DW);   // straight from the workspace
+        const u32 bA = row[byte_of(xA, g * 16u)], bB = row[byte_of(xB, g * 16u) + 1u];
+        step_back(RA, xA, bA, pos);
+        step_back(RB, xB, bB, pos);
+        pos = pos == SB - 1 ? 0u : pos + 1u;
+        const int j = tt - SB;
         if ((j & 7) == 0) { outA[j >> 3] = (uint8_t)(RA >> 24); outB[j >> 3] = (uint8_t)(RB >> 24); }
     };
 
-    int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
-    while (t >= SB && (t & (ITER - 1)) != 7) slow_step(t--);    // down to t = 7 mod 32: phases and output dwords line up
+    while (t >= SB && (t & (ITER - 1)) != CT) slow_step(t--);   // down to the top of an iteration
     if (t - (ITER - 1) >= SB) {
         // uniform row bases of the wave's four tiles
         const uint8_t* tb[4];
@@ -1033,15 +1044,18 @@ VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
             const u32 tr = blockIdx.x * 4u + (u32)jj;
             tb[jj] = (const uint8_t*)(a.ws + (size_t)(tr < n_tiles ? tr : n_tiles - 1) * a.ws_tile_stride);
         }
-        auto fill = [&](int slot, int step) __attribute__((always_inline)) {
+        auto fill = [&](int slot, int row) __attribute__((always_inline)) {
             // scalar tile base + ONE 32-bit per-lane offset for the four loads (a tile's rows stay below 4 GiB)
-            const u32 vo = src_off + (u32)(step < 0 ? 0 : step) * 1024u;
+            const u32 vo = src_off + (u32)(row < 0 ? 0 : row) * 1024u;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(ring + (slot * 4 + jj) * 64), 16, 0, 0);
         };
+        // t = CT mod 32: row t / SPS sits in slot (CT / SPS) % D in every iteration (an iteration retires ROWS_IT rows, a
+        // multiple of D)
+        constexpr int S0 = (CT / SPS) % D;
 #pragma unroll
-        for (int k = 0; k < D; ++k) fill(k, t - k);
+        for (int k = 0; k < D; ++k) fill((S0 - k + D) % D, t / SPS - k);
         const uint8_t* ring_b = (const uint8_t*)ring;
         while (t - (ITER - 1) >= SB) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): retire the previous flush (and the ring)
@@ -1050,21 +1064,33 @@ VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
             for (; it < KI && t - (ITER - 1) >= SB; ++it, t -= ITER) {
 #pragma unroll
                 for (int pk = 0; pk < ITER; ++pk) {
-                    const int k = pk % D;                        // ring slot
-                    const u32 ph1 = (u32)((8 - pk % 8) % 8);     // step t - pk, t = 7 mod 8: (t - pk + 1) % 8
-                    // the slot's four loads are the oldest of the 4 D in flight
+                    // step t - pk = CT - pk mod 32: its row is rk rows below the iteration's top row, step sidx of it
+                    const int cs = CT - pk;                      // may go negative inside an iteration
+                    const int rk = CT / SPS - (cs >= 0 ? cs / SPS : -((-cs + SPS - 1) / SPS));
+                    const int sidx = ((cs % SPS) + SPS) % SPS;
+                    const int slot = ((S0 - rk) % D + D) % D;
+                    // the row's four loads are the oldest of the 4 D in flight
                     constexpr int NV = 4 * (D - 1);
                     __builtin_amdgcn_s_waitcnt(0x0F70 | (NV & 15) | ((NV >> 4) << 14));   // vmcnt(4 D - 4)
-                    const u32 dA = __builtin_amdgcn_perm(RA, RA, 0x0c0c0303u), dB = __builtin_amdgcn_perm(RB, RB, 0x0c0c0303u);   // state | state << 8
-                    const u32 aA = pair_base + 256u * __builtin_amdgcn_ubfe(dA, ph1 + 6, 2) + 2u * __builtin_amdgcn_ubfe(dA, ph1 + 3, 3);
-                    const u32 aB = pair_base + 256u * __builtin_amdgcn_ubfe(dB, ph1 + 6, 2) + 2u * __builtin_amdgcn_ubfe(dB, ph1 + 3, 3);
-                    const u32 wA = ring_b[k * 4096 + aA], wB = ring_b[k * 4096 + 1 + aB];
-                    pick(RA, wA, __builtin_amdgcn_ubfe(dA, ph1, 3));
-                    pick(RB, wB, __builtin_amdgcn_ubfe(dB, ph1, 3));
-                    // the refill overwrites what the two reads above fetched: they have returned (their bits are in RA / RB)
-                    asm volatile("" : "+v"(RA), "+v"(RB) : : "memory");
-                    fill(k, t - pk - D);
-                    __builtin_amdgcn_sched_barrier(0);
+                    const u32 wA = ring_b[slot * 4096 + sidx * 4 * DW + byte_of(xA, pair_base)];
+                    const u32 wB = ring_b[slot * 4096 + sidx * 4 * DW + 1 + byte_of(xB, pair_base)];
+                    if constexpr (ITER % SB == 0) {
+                        // the replaced bit's position is a compile-time constant: (SB - (t - pk + 1) % SB) % SB with
+                        // t = CT mod SB (SB divides 32)
+                        const u32 p = (u32)((SB - (((CT - pk + 1) % SB) + SB) % SB) % SB);
+                        step_back(RA, xA, wA, p);
+                        step_back(RB, xB, wB, p);
+                    } else {
+                        step_back(RA, xA, wA, pos);
+                        step_back(RB, xB, wB, pos);
+                        pos = pos == SB - 1 ? 0u : pos + 1u;
+                    }
+                    if (sidx == 0) {
+                        // the row is done and its reads have returned (their bits are in RA / RB): refill the slot
+                        asm volatile("" : "+v"(RA), "+v"(RB), "+v"(xA), "+v"(xB) : : "memory");
+                        fill(slot, (t - pk) / SPS - D);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 // bytes j/8 of the 32 steps, first decoded bit of each byte on top: RA's top byte is the LOWEST byte index
                 obuf[it * 64 + lane] = __builtin_amdgcn_perm(RA, RA, 0x00010203u);
@@ -1078,6 +1104,7 @@ VIT_DEV void reg_chainback64_body(const RegChainbackArgs& a) {
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring's last (surplus) loads land before LDS is released
+        if constexpr (ITER % SB == 0) pos = (SB - (u32)(t + 1) % (u32)SB) % SB;
     }
     while (t >= SB) slow_step(t--);
 }
@@ -1343,7 +1370,7 @@ template <class SP>
 constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 : 2; }
 // K = 9, R = 2: capped at 240 registers (the attribute counts in halves of the unified file: 120).  hipcc's schedule for 256
 // holds no more live values than fit 240 (no scratch either way), the capped kernel runs 2.7 % FASTER (10.99 vs 11.29 ms,
-// 65536 x 8192) and two of its waves leave 32 registers per SIMD: the K = 9 chainback's allocation (reg_chainback64_body)
+// 65536 x 8192) and two of its waves leave 32 registers per SIMD: the K = 9 chainback's allocation (reg_chainback_ring_body)
 // (the attribute takes a literal, not a template-dependent value: the translation unit of the code sets it -- reg_inst.hip
 // with -DVIT_REG_ID=3, reg_jit.hpp for a run-time compiled K = 9, R = 2 code)
 #if !defined(VIT_REG_UPDATE_VGPR_CAP) && defined(VIT_REG_ID)
@@ -1364,7 +1391,7 @@ template <class SP>
 VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
     if constexpr (SP::LANE_BITS == 0) reg_chainback0_body<SP>(a);
     else if constexpr (SP::NREG == 16) reg_chainback16_body<SP>(a);
-    else if constexpr (SP::NREG == 64) reg_chainback64_body<SP>(a);
+    else if constexpr (SP::NREG == 64) reg_chainback_ring_body<SP>(a);
     else reg_chainback_coop_body<SP>(a);
 }
 template <class SP>
@@ -1379,12 +1406,23 @@ __global__ void __launch_bounds__(64, reg_chainback_min_waves<SP>()) reg_chainba
     if (a.wave_priority) __builtin_amdgcn_s_setprio(3);
     reg_chainback_body<SP>(a);
 }
-// K = 9 alone on the device with a batch too small to be bandwidth bound: the cooperative body (one wave per 32 frames: four times
-// the waves, no direct-to-LDS issue cost on the chase's path -- 8192 frames x 8192 bits 0.79 ms against 1.20 ms; level at 65536)
+// The body reg_chainback_kernel does NOT run, as a kernel of its own (both are 128 / 32 frames per block as their bodies say):
+//  K = 9: the cooperative body, for a batch too small to be bandwidth bound decoded alone on the device (one wave per 32
+//         frames: four times the waves, no direct-to-LDS issue cost on the chase's path -- 8192 frames x 8192 bits 0.79 ms
+//         against 1.20 ms; level at 65536);
+//  K = 7: the LDS-ring body -- measured and NOT used: with an LDS round trip on the dependent chain it is slower than the
+//         register ring alone (0.86 / 0.71 / 0.68 ms against 0.80 / 0.52 / 0.49 at 65536 / 32768 / 8192 frames) and far slower
+//         beside update waves (65536 x 8192 through the pipeline 115 against 150 Gbit/s; three update streams of 32768-frame
+//         sub-batches, which its 28 registers would allow: 109 against 144).  Kept selectable for tests and experiments.
 template <class SP>
-__global__ void __launch_bounds__(64, 2) reg_chainback_coop_kernel(RegChainbackArgs a) {
-    if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);
+VIT_DEV void reg_chainback_alt_body(const RegChainbackArgs& a) {
+    if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);                              // 32 frames per wave
+    else if constexpr (SP::NREG == 16 && SP::LANE_BITS == 2) reg_chainback_ring_body<SP>(a);   // 128 frames per wave
 }
+template <class SP>
+constexpr int reg_chainback_alt_min_waves() { return SP::NREG == 16 ? 1 : 2; }
+template <class SP>
+__global__ void __launch_bounds__(64, reg_chainback_alt_min_waves<SP>()) reg_chainback_coop_kernel(RegChainbackArgs a) { reg_chainback_alt_body<SP>(a); }
 // frames up to which reg_chainback() prefers it when the kernel runs alone
 constexpr size_t REG_CHAINBACK64_COOP_MAX_FRAMES = 32768;
 template <class SP>
@@ -1406,7 +1444,7 @@ struct RegJitModule {
     hipFunction_t update[2] = {nullptr, nullptr};   // [0] 16-bit, [1] 8-bit metrics/symbols
     hipFunction_t resume[2] = {nullptr, nullptr};
     hipFunction_t chainback = nullptr, export_ = nullptr;
-    hipFunction_t chainback_coop = nullptr;         // K = 9 only: reg_chainback_coop_kernel, 32 frames per block
+    hipFunction_t chainback_coop = nullptr;         // K = 7, 9: the alternative body (reg_chainback_alt_body)
     unsigned chainback_frames_per_block = 32;
 };
 
@@ -1485,6 +1523,7 @@ template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsi
     using SP = RegSpecOf<VIT_REG_ID>::type;
     constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
     if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1619,9 +1658,10 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     // K = 9: the LDS-streaming body beside an update kernel (it fits the registers two update waves leave and costs them no
     // issue slots) and for batches that are bandwidth bound anyway, the cooperative body for a small batch on its own
     bool coop = rc.K == 9 && !beside_update && frames <= REG_CHAINBACK64_COOP_MAX_FRAMES;
-    if (const char* e = getenv("VIT_HIP_CHAINBACK_COOP")) coop = rc.K == 9 && *e == '1';   // tests: either body at any size
+    if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';   // tests: either body at any size
     if (rc.jit) {
-        if (coop && rc.jit->chainback_coop) return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), tiles, 64, st);
+        if (coop && rc.jit->chainback_coop)
+            return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st);
         const unsigned fpb = rc.jit->chainback_frames_per_block;
         return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st);
     }

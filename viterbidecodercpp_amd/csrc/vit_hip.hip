@@ -1029,13 +1029,18 @@ static int vit_hip_shader_clock_mhz_impl(int device, double* mhz_out, double* cy
     int cus = 0, wall_khz = 0;
     VIT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
-    // four waves on every SIMD of the chip (one 256-thread workgroup per SIMD), about 2 ms of packed adds at 2.4 GHz
-    const unsigned blocks = (unsigned)(cus > 0 ? cus : 256) * 4u, iters = 4000;
-    const size_t waves = (size_t)blocks * 4;
+    // with the issue rate asked for: four waves on every SIMD of the chip (one 256-thread workgroup per SIMD), about 2 ms of
+    // packed adds at 2.4 GHz.  Clock only: ONE wave per CU -- a probe that can run beside other kernels without adding a chip
+    // full of vector work to their power draw (the card lowers its clock under it: 1.96 GHz read by the heavy probe beside the
+    // K7 pipeline against 2.3 GHz by this one)
+    const bool light = cycles_per_pk_instr_out == nullptr;
+    const unsigned threads = light ? 64u : 256u;
+    const unsigned blocks = (unsigned)(cus > 0 ? cus : 256) * (light ? 1u : 4u), iters = 4000;
+    const size_t waves = (size_t)blocks * (threads / 64u);
     uint64_t* d_out = nullptr;
     VIT_HIP_CHECK(hipMalloc((void**)&d_out, waves * 2 * sizeof(uint64_t)));
     std::vector<uint64_t> host(waves * 2);
-    hipLaunchKernelGGL(vit::shader_clock_kernel, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 3u);
+    hipLaunchKernelGGL(vit::shader_clock_kernel, dim3(blocks), dim3(threads), 0, nullptr, d_out, iters, 3u);
     const hipError_t e1 = hipGetLastError();
     const hipError_t e2 = hipMemcpy(host.data(), d_out, waves * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
