@@ -97,7 +97,33 @@ def test_k9_update_kernels_do_not_spill(tmp_path, reg_id):
     for k in upd:
         assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         if reg_id == 3:
-            assert usage[k]["VGPRs"] + usage[k].get("AGPRs", 0) <= 256, (k, usage[k])
+            # capped at 240 (amdgpu_num_vgpr(120)): two update waves leave 32 registers of a SIMD's 512 for the chainback
+            assert usage[k]["VGPRs"] + usage[k].get("AGPRs", 0) <= 240, (k, usage[k])
+
+
+def test_k9_chainback_streams_rows_through_lds_and_fits_beside_two_update_waves(tmp_path):
+    """the K = 9 chainback must fit the 32 registers two 240-register update waves leave on a SIMD, its rows must arrive by
+    direct-to-LDS loads (no register ring), its main loop must keep counted vmcnt waits, and three of its one-wave workgroups
+    plus eight update waves must fit a CU's 160 KiB of LDS."""
+    asm, usage = _compile("reg_inst.hip", ["-DVIT_REG_ID=3"], tmp_path)
+    cb = [k for k in usage if "reg_chainback_kernel" in k]
+    upd = [k for k in usage if "reg_update_kernel" in k]
+    assert len(cb) == 1 and len(upd) == 2
+    u = usage[cb[0]]
+    assert u["VGPRs"] + u.get("AGPRs", 0) <= 32 and u["ScratchSize"] == 0, u
+    # a 65536-frame batch is 512 of these workgroups on 256 CUs: three of them must still leave a CU's eight update waves their LDS
+    assert 3 * u["LDS"] + 8 * max(usage[k]["LDS"] for k in upd) <= 160 * 1024, (u, [usage[k]["LDS"] for k in upd])
+    body = _kernel_body(asm, r"_ZN3vit20reg_chainback_kernel\w+")
+    lines, loops = _inner_loops(body)
+    main = max(loops, key=lambda ab: sum("global_load_lds_dwordx4" in l for l in lines[ab[0]:ab[1] + 1]))
+    text = "\n".join(lines[main[0]:main[1] + 1])
+    assert text.count("global_load_lds_dwordx4") >= 128 and "global_load_dwordx4" not in text      # 32 steps x 4 tiles
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
+    # one counted wait per step (hipcc drops the few that an earlier wait already implies); a drain only where the flush is
+    assert waits.count("28") >= 24 and waits.count("0") <= 1 and set(waits) <= {"0", "28"}, waits
+    # the alternative (cooperative) kernel keeps its own budget
+    coop = [k for k in usage if "reg_chainback_coop_kernel" in k]
+    assert len(coop) == 1 and usage[coop[0]]["ScratchSize"] == 0
 
 
 def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):

@@ -170,10 +170,10 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     (7, 2, (0o171, 0o133), "HARD8"),         # run-time instantiation
 ])
 def test_chainback_bodies(oracle, monkeypatch, K, R, G, decode_type, alt):
-    """K = 7 and K = 9 have two chainback kernels each -- rows streamed through an LDS ring (K = 9: beside an update kernel and
-    for large batches; K = 7: experiments only) and a register-ring / cooperative one (K = 7: always; K = 9: small batches
-    alone): each is forced here at sizes the library would give to the other, with trace lengths that leave ragged ends above
-    and below the 32-step iterations, frame counts that are no multiple of a wave's 128, and per-frame end states."""
+    """K = 7 and K = 9 have two chainback kernels each -- rows streamed through an LDS ring (K = 9: the one in use; K = 7:
+    experiments only) and a register-ring / cooperative one (K = 7: the one in use; K = 9: the alternative): both are run here,
+    with trace lengths that leave ragged ends above and below the 32-step iterations, frame counts that are no multiple of a
+    wave's 128, and per-frame end states."""
     monkeypatch.setenv("VIT_HIP_CHAINBACK_ALT", alt)
     code = Code(f"K{K}R{R}", K, R, tuple(G))
     rng = np.random.default_rng(R)

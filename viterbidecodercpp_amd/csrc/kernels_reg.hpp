@@ -977,7 +977,7 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
     constexpr int ROWS_IT = ITER / SPS;                        // rows an iteration retires
     // ring depth in rows (divides ROWS_IT).  K = 9, beside an update kernel: 4, 8 and 16 rows move the same bytes per second
     // (the chase waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keep update waves off the CU (12.6 ->
-    // 14.1 ms per batch); alone on the device a small batch runs 1.67 / 1.20 / 0.96 ms (8192 frames x 8192 bits)
+    // 14.1 ms per batch)
     constexpr int D = 8;
     static_assert(ROWS_IT % D == 0, "ring slots are compile-time constants");
     constexpr int KI = 16;                                     // iterations between flushes: 64 output bytes per frame
@@ -1044,12 +1044,18 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
             const u32 tr = blockIdx.x * 4u + (u32)jj;
             tb[jj] = (const uint8_t*)(a.ws + (size_t)(tr < n_tiles ? tr : n_tiles - 1) * a.ws_tile_stride);
         }
+        // the ring's LDS address, opaque to hipcc: a direct-to-LDS load whose destination it can name (the array's base: slot 0)
+        // makes it guard every later read of the array that it cannot tell apart with s_waitcnt vmcnt(0) -- one full drain of
+        // the ring per pass, in front of the read that follows the refill of slot 0
+        typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+        u32 ring_lds = (u32)(uintptr_t)(lds_u8_t*)ring;
+        asm volatile("" : "+s"(ring_lds));
         auto fill = [&](int slot, int row) __attribute__((always_inline)) {
             // scalar tile base + ONE 32-bit per-lane offset for the four loads (a tile's rows stay below 4 GiB)
             const u32 vo = src_off + (u32)(row < 0 ? 0 : row) * 1024u;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(ring + (slot * 4 + jj) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(lds_u8_t*)(uintptr_t)(ring_lds + (u32)(slot * 4 + jj) * 1024u), 16, 0, 0);
         };
         // t = CT mod 32: row t / SPS sits in slot (CT / SPS) % D in every iteration (an iteration retires ROWS_IT rows, a
         // multiple of D)
@@ -1406,14 +1412,16 @@ __global__ void __launch_bounds__(64, reg_chainback_min_waves<SP>()) reg_chainba
     if (a.wave_priority) __builtin_amdgcn_s_setprio(3);
     reg_chainback_body<SP>(a);
 }
-// The body reg_chainback_kernel does NOT run, as a kernel of its own (both are 128 / 32 frames per block as their bodies say):
-//  K = 9: the cooperative body, for a batch too small to be bandwidth bound decoded alone on the device (one wave per 32
-//         frames: four times the waves, no direct-to-LDS issue cost on the chase's path -- 8192 frames x 8192 bits 0.79 ms
-//         against 1.20 ms; level at 65536);
+// The body reg_chainback_kernel does NOT run, as a kernel of its own (128 / 32 frames per block as the bodies say).  Selected
+// with VIT_HIP_CHAINBACK_ALT=1: tests and experiments only.
+//  K = 9: the cooperative body (one wave per 32 frames; every q-lane repeats the chase and a ds_bpermute picks the owner's bit:
+//         34 vector instructions per step for 32 frames, 92 registers).  Level with the ring body alone on the device (8192 /
+//         32768 / 65536 frames x 8192 bits: 0.79 / 1.50 / 2.96 ms against 0.76 / 1.52 / 2.9 - 3.0), no use beside two update
+//         waves (registers, issue slots);
 //  K = 7: the LDS-ring body -- measured and NOT used: with an LDS round trip on the dependent chain it is slower than the
-//         register ring alone (0.86 / 0.71 / 0.68 ms against 0.80 / 0.52 / 0.49 at 65536 / 32768 / 8192 frames) and far slower
-//         beside update waves (65536 x 8192 through the pipeline 115 against 150 Gbit/s; three update streams of 32768-frame
-//         sub-batches, which its 28 registers would allow: 109 against 144).  Kept selectable for tests and experiments.
+//         register ring alone (0.82 / 0.65 / 0.63 ms against 0.80 / 0.52 / 0.49 at 65536 / 32768 / 8192 frames) and far slower
+//         beside update waves (65536 x 8192 through the pipeline 115 - 123 against 150 - 154 Gbit/s; three update streams of
+//         32768-frame sub-batches, which its 28 registers would allow: 109 against 144).
 template <class SP>
 VIT_DEV void reg_chainback_alt_body(const RegChainbackArgs& a) {
     if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);                              // 32 frames per wave
@@ -1423,8 +1431,6 @@ template <class SP>
 constexpr int reg_chainback_alt_min_waves() { return SP::NREG == 16 ? 1 : 2; }
 template <class SP>
 __global__ void __launch_bounds__(64, reg_chainback_alt_min_waves<SP>()) reg_chainback_coop_kernel(RegChainbackArgs a) { reg_chainback_alt_body<SP>(a); }
-// frames up to which reg_chainback() prefers it when the kernel runs alone
-constexpr size_t REG_CHAINBACK64_COOP_MAX_FRAMES = 32768;
 template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 
@@ -1644,7 +1650,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
 }
 
 inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
-                         hipStream_t st, unsigned wave_priority = 0, bool beside_update = false) {
+                         hipStream_t st, unsigned wave_priority = 0) {
     if (frames == 0 || L == 0) return 0;
     RegChainbackArgs a{};
     a.ws = (const uint4*)d_ws;
@@ -1655,10 +1661,9 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.L = (u32)L;
     a.wave_priority = wave_priority;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
-    // K = 9: the LDS-streaming body beside an update kernel (it fits the registers two update waves leave and costs them no
-    // issue slots) and for batches that are bandwidth bound anyway, the cooperative body for a small batch on its own
-    bool coop = rc.K == 9 && !beside_update && frames <= REG_CHAINBACK64_COOP_MAX_FRAMES;
-    if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';   // tests: either body at any size
+    // K = 7, 9: the other chainback kernel of the code (reg_chainback_alt_body) -- tests and experiments only
+    bool coop = false;
+    if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';
     if (rc.jit) {
         if (coop && rc.jit->chainback_coop)
             return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st);

@@ -523,7 +523,7 @@ int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t 
 }
 
 static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
-                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority, bool beside_update = false) {
+                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (frames == 0 || L == 0) return VIT_HIP_OK;
     if (!d_workspace || !d_bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "d_workspace/d_bytes_out is NULL");
@@ -531,7 +531,7 @@ static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (h->plan == VIT_HIP_PLAN_REG) {
-        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority, beside_update);
+        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
         return VIT_HIP_OK;
     }
@@ -751,7 +751,7 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
             VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
         }
         if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
-        rc = chainback_batch_impl(p->h, p->ws[k], nf, p->L, out, es, s_cb, p->cb_wave_priority, /*beside_update=*/true);
+        rc = chainback_batch_impl(p->h, p->ws[k], nf, p->L, out, es, s_cb, p->cb_wave_priority);
         if (rc != VIT_HIP_OK) return rc;
         if (p->timing) {
             VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
