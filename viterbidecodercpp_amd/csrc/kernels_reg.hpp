@@ -792,6 +792,13 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             else block(std::true_type{});
         }
     } else {
+        // Enter the loop with NO memory operation pending.  hipcc places one s_waitcnt vmcnt(N) per use for both ways into the
+        // loop header and must take the stricter: coming from the prologue, the symbols the first block needs are the youngest
+        // loads, so the steady state inherited vmcnt(2) where ten younger stores and loads may stay in flight -- every block
+        // waited for loads issued four steps earlier and for all but the last two decision stores (K = 9; K = 7: vmcnt(7..15)
+        // instead of 16 / 17).  With the drain the waits are what the ring depth allows; the kernels' times did not move (alone
+        // or beside a chainback: the loads were back in time anyway), the margin against memory latency did
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         for (; t0 + U <= a.t_end; t0 += U, ws_blk += (U / SPS) * 64) block(std::false_type{});
         if (t0 < a.t_end) block(std::true_type{});
     }
