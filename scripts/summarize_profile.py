@@ -68,11 +68,12 @@ if stats:
             if "vit::" in r["Kernel_Name"]:
                 per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         steps = int(os.environ.get("PROFILE_STEPS", "20"))
-        lines += [f"Launch by launch (same pass; bench.py times the last {steps} launches of each kernel, the ones before are warm-up):", "",
+        warm = int(os.environ.get("PROFILE_WARMUP", "10"))
+        lines += [f"Launch by launch (same pass; of each kernel's launches bench.py times {steps} after {warm} warm-up ones; those behind them are the untimed batches of its clock-under-load probe):", "",
                   "| kernel | launches | avg ms, timed launches only | median ms | first launch ms |", "|---|---|---|---|---|"]
         for k, v in per.items():
-            if len(v) > steps:
-                t = sorted(v[-steps:])
+            if len(v) >= warm + steps:
+                t = sorted(v[warm:warm + steps])
                 lines.append(f"| `{k}` | {len(v)} | {sum(t)/len(t):.3f} | {t[len(t)//2]:.3f} | {v[0]:.3f} |")
         lines.append("")
 
