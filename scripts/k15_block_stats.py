@@ -6,7 +6,7 @@ from collections import Counter
 s = open(sys.argv[1]).read()
 K = sys.argv[2] if len(sys.argv) > 2 else "15"
 RT = sys.argv[3] if len(sys.argv) > 3 else ("6" if K == "15" else "0")
-m = re.search(r'^(_ZN3vit18lds2_update_kernelILi' + K + r'ELi0ELi' + RT + r'EEEvNS_14Lds2UpdateArgsE):', s, re.M)
+m = re.search(r'^(_ZN3vit\d+lds2_update_kernel(?:_c120)?ILi' + K + r'ELi0ELi' + RT + r'EEEvNS_14Lds2UpdateArgsE):', s, re.M)
 body = s[m.end():s.index('.Lfunc_end', m.end())]
 segs, seg = [], []
 for l in body.split('\n') + ['s_barrier']:

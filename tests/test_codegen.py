@@ -128,20 +128,26 @@ def test_k9_chainback_streams_rows_through_lds_and_fits_beside_two_update_waves(
 
 def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
     asm, usage = _compile("vit_hip.hip", [], tmp_path)
-    k15 = [k for k in usage if "lds2_update_kernelILi15ELi0ELi6" in k]      # the Cassini instantiation (compile-time rate 6)
+    k15 = [k for k in usage if "lds2_update_kernel_c120ILi15ELi0ELi6" in k]  # the Cassini instantiation (compile-time rate 6)
     assert len(k15) == 1
     u = usage[k15[0]]
-    for k in usage:                                                           # every large-K instantiation stays out of scratch
-        if "lds2_update_kernel" in k:
+    cb = [k for k in usage if "lds2_chainback_kernel" in k]
+    assert len(cb) == 1
+    for k in usage:                                             # every other large-K instantiation stays out of scratch
+        if "lds2_update_kernel" in k and k != k15[0] and "ILi15ELi8ELi6" not in k:
             assert usage[k]["ScratchSize"] == 0, (k, usage[k])
-    # 512 threads per workgroup, two workgroups per CU = 4 waves per SIMD: 128 registers at most
-    assert u["VGPRs"] + u.get("AGPRs", 0) <= 128, u
+        if "lds2_update_kernel_c120" in k:
+            # 512 threads per workgroup, two workgroups per CU = 4 waves per SIMD of 120 registers, and the chainback kernel's
+            # allocation (granules of 8) beside them: 512 per SIMD
+            assert 4 * 120 + 8 * -(-usage[cb[0]]["VGPRs"] // 8) <= 512 and usage[k]["VGPRs"] + usage[k].get("AGPRs", 0) <= 120, (k, usage[k])
+    # (the 8-bit Cassini instantiation pays the cap with 16 bytes of scratch; the 16-bit one -- BASELINE configs[4] -- with none
+    # since the table build forms its lane number afresh)
     # two radix-16 groups per thread sit right at that budget, and since the block loop's control flow is scalar (step range
     # pinned uniform, the careful flag carried as a dword through v_readfirstlane) nothing is left in scratch; the fast
     # block (the code between two workgroup barriers that holds the 64 table reads and the eight 16-byte metric stores; ONE
     # copy serves both table sets) neither spills nor reloads
     assert u["ScratchSize"] == 0, u
-    body = _kernel_body(asm, r"_ZN3vit18lds2_update_kernelILi15ELi0ELi6EEEvNS_14Lds2UpdateArgsE")
+    body = _kernel_body(asm, r"_ZN3vit23lds2_update_kernel_c120ILi15ELi0ELi6EEEvNS_14Lds2UpdateArgsE")
     seg, fast = [], []
     for l in body.split("\n") + ["s_barrier"]:
         if "s_barrier" in l:

@@ -231,7 +231,7 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (2, "HARD8", 32768, 256, (3, 2, 1)),     # the largest batch of that schedule on an MI355X (4 x 256 CUs x 32 frames)
     (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
     (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
-    (7, "SOFT16", 24, 256, (2, 1, 0)),       # K = 15 (PLAN_LDS2): back to back
+    (7, "SOFT16", 24, 256, (2, 1, 1)),       # K = 15 (PLAN_LDS2, update capped at 120 registers): chainback beside the next update
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9, R = 4: one update wave takes 360 registers, so the batch goes in sub-batches of 32768
 ])

@@ -169,7 +169,7 @@ struct Lds2Geom {
 // RT: the code rate as a compile-time constant (the Cassini instantiation: the six per-symbol loops lose their run-time bound
 // checks and the phi copies around them), or 0 = taken from the arguments (any R <= 6).
 template <int K, int SHIFT, int RT = 0>
-__global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update_kernel(Lds2UpdateArgs a) {
+__device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     using GM = Lds2Geom<K>;
     constexpr int N = GM::N, T = GM::T, G = GM::G, GPT = GM::GPT, NW = GM::NW, BLK = GM::BLK, SBITS = GM::SBITS;
     constexpr u32 BIAS2 = 0x80008000u;
@@ -290,13 +290,17 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     }
     auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
         u32 e = 0, eb = 0;
-        const u32 pb = (u32)lane ^ xb;
+        // the lane number is formed again here (two instructions, pinned): kept across the block it is one of the two values the
+        // 120-register cap sends to scratch, reloaded behind a full vmcnt(0) right in front of the build
+        u32 ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        l2_opaque(ln);
+        const u32 pb = ln ^ xb;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
-                e = l2_add(e, ((lane >> i) & 1) ? a1 : a0);
+                e = l2_add(e, ((ln >> i) & 1) ? a1 : a0);
                 eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
             }
         }
@@ -687,6 +691,20 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
     }
 }
 
+template <int K, int SHIFT, int RT = 0>
+__global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update_kernel(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
+// The same body capped at 120 registers (the attribute counts in halves of the unified file), used for K = 11, 14, 15: four
+// 125..128-register waves fill a SIMD's 512, four 120-register ones leave 32 -- the chainback kernel's 24, which then runs
+// beside the next batch's update instead of behind it.  All of them fit the cap without scratch (the 8-bit Cassini
+// instantiation alone pays 16 bytes) once the table build forms its lane number afresh instead of keeping it; alone the capped
+// Cassini kernel is 0.6 % slower (49.2 -> 49.5 ms), the overlap hides 2.3 ms of chainback: 51.6 -> 50.1 - 50.3 ms per 4096 x 8192
+// batch.  (K = 12 needs 98 registers anyway; K = 13 and 16 would spill.)
+template <int K, int SHIFT, int RT = 0>
+__global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) __attribute__((amdgpu_num_vgpr(60)))
+lds2_update_kernel_c120(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
+// codes whose update kernel leaves room for a chainback wave on every SIMD (the pipeline overlaps their chainback)
+inline bool lds2_chainback_fits_beside_update(int K) { return K == 11 || K == 12 || K == 14 || K == 15; }
+
 // ---- chainback / export on the PLAN_LDS2 layout -------------------------------------------------------------------
 struct Lds2ChainbackArgs {
     const u32* ws;
@@ -791,7 +809,10 @@ inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
 template <int K, int SHIFT>
 int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) {
     using GM = Lds2Geom<K>;
-    auto kern = (K == 15 && a.R == 6) ? lds2_update_kernel<K, SHIFT, (K == 15 ? 6 : 0)> : lds2_update_kernel<K, SHIFT, 0>;
+    void (*kern)(Lds2UpdateArgs) = nullptr;
+    if constexpr (K == 15) kern = (a.R == 6) ? lds2_update_kernel_c120<K, SHIFT, 6> : lds2_update_kernel_c120<K, SHIFT, 0>;
+    else if constexpr (K == 11 || K == 14) kern = lds2_update_kernel_c120<K, SHIFT, 0>;
+    else kern = lds2_update_kernel<K, SHIFT, 0>;
     if (GM::smem_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)GM::smem_bytes) != hipSuccess)

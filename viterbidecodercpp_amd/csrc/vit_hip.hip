@@ -660,9 +660,11 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     p->h = h; p->max_frames = max_frames; p->L = L;
     // Rule 1 -- chainback beside the next update.  The overlap pays while the update leaves register file and issue slots
     // free: PLAN_REG with at most two update waves per SIMD (a 140-register wave; the chainback's 166 make a third resident).
-    // A larger batch fills the SIMDs by itself, and the PLAN_LDS2 / PLAN_LDS update takes whole CUs: there a chainback in the
-    // way only costs (measured: K7 131072 frames 8.70 ms overlapped vs 8.10 ms back to back; K15 55.1 vs 54.8), so those
-    // batches run back to back on one stream.
+    // A larger batch fills the SIMDs by itself (measured: K7 131072 frames 8.70 ms overlapped vs 8.10 ms back to back), and the
+    // PLAN_LDS update takes whole CUs: those batches run back to back on one stream.  PLAN_LDS2 at K = 11, 12, 14, 15: the
+    // update kernel is capped at 120 registers, so the 24-register chainback finds room on every SIMD beside four update
+    // waves and runs beside the next batch's update (K15 4096 x 8192: 51.6 -> 50.3 ms per batch; with the 128-register update
+    // the same overlap gained 0.3 ms).
     // Rule 2 -- two updates in flight.  A batch of at most ONE update wave per SIMD (frames <= 4 x CUs x tile: the 32768-frame
     // share of BASELINE configs[3]) issues at the one-wave rate (5.27 cycles per packed instruction against 4.52 with two
     // waves, profiles/r2_dep_rate.txt): a second update stream and a third workspace put the next batch's update beside it
@@ -673,6 +675,9 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         const size_t per_wave = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
         p->overlap_max_frames = 2 * per_wave;
         p->two_updates_max_frames = per_wave;
+        // PLAN_LDS2 codes whose update kernel is capped at 120 registers: the 24-register chainback fits beside four of its waves
+        if (h->plan == VIT_HIP_PLAN_LDS2 && vit::lds2_chainback_fits_beside_update(h->K)) p->overlap_max_frames = (size_t)-1;
+        if (const char* o = getenv("VIT_HIP_PIPELINE_OVERLAP")) p->overlap_max_frames = *o == '1' ? (size_t)-1 : *o == '0' ? 0 : p->overlap_max_frames;   // experiments only
         const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
         if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
     }
