@@ -175,11 +175,16 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream;
  *     (and the chainback kernel at a higher wave priority than the updates: between two staggered update kernels it would
  *     otherwise get the issue slots both leave over and become the bottleneck);
- *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9): a batch of up
- *     to two waves per SIMD is fed to the kernels as SUB-BATCHES of one wave per SIMD through the same three-workspace,
- *     two-update-stream schedule (K = 9, 65536 frames: 14.2 -> 12.0 ms per batch);
- *   - larger batches and the LDS plans fill the CUs by themselves, a chainback in their way costs more than it hides:
- *     one stream, update and chainback back to back. */
+ *     (K = 9, R = 2 as well: its update kernel is capped at 240 registers and its chainback streams the decision rows
+ *     through LDS in 24, so two update waves and a chainback wave share a SIMD: 65536 frames 13.3 -> 12.4-13.0 ms per batch);
+ *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9, R = 4: 360
+ *     registers per wave): a batch of up to two waves per SIMD is fed to the kernels as SUB-BATCHES of one wave per SIMD
+ *     through the same three-workspace, two-update-stream schedule;
+ *   - PLAN_LDS2 at K = 11, 12, 14, 15: the update kernel is capped at 120 registers, which leaves the chainback kernel's 24
+ *     on every SIMD beside four update waves: two workspaces, chainback beside the next update (K = 15, 4096 frames:
+ *     51.6 -> 50.2 ms per batch);
+ *   - larger register-plan batches, K = 13, 16 and PLAN_LDS fill the CUs by themselves, a chainback in their way costs more
+ *     than it hides: one stream, update and chainback back to back. */
 typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
 typedef struct vit_hip_pipeline_schedule {
     int32_t workspaces;             /* decision workspaces owned (2 or 3) */

@@ -6,7 +6,7 @@ python bench.py --config 2 --steps 10 --warmup 3 > gpurun_out/r3_bench_k9.json 2
 python bench.py --config 4 --steps 5 --warmup 2 > gpurun_out/r3_bench_k15.json 2>> gpurun_out/r3_bench.err; echo "k15 rc=$?"
 python bench.py --config 1 --steps 20 --warmup 5 --via python --no-cpu-baseline > gpurun_out/r3_bench_default_via_python.json 2>> gpurun_out/r3_bench.err; echo "python-route rc=$?"
 python bench.py --gpus 2 --share-gpu --backend gloo --frames 32768 --steps 10 --warmup 3 2>> gpurun_out/r3_bench.err | grep '^{' > gpurun_out/r3_bench_2rank_share_gpu.json; echo "2rank rc=$?"
-PROFILE_STEPS=10 PROFILE_WARMUP=4 bash scripts/profile.sh r3_k9 --config 2 > /dev/null
+[ -n "${BENCH_LINES_PROFILE:-}" ] && PROFILE_STEPS=${PROFILE_STEPS:-10} PROFILE_WARMUP=${PROFILE_WARMUP:-4} bash scripts/profile.sh ${BENCH_LINES_PROFILE} > /dev/null
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r3_bench_*.json")):
