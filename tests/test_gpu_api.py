@@ -232,6 +232,9 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
     (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
     (7, "SOFT16", 24, 256, (2, 1, 1)),       # K = 15 (PLAN_LDS2, update capped at 120 registers): chainback beside the next update
+    ((11, 2, (0o3345, 0o3613)), "SOFT16", 40, 128, (2, 1, 1)),    # K = 11: the same
+    ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 0)),  # K = 13 (139 registers, three waves per SIMD): back to back
+    ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 10 (PLAN_LDS): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9, R = 4: one update wave takes 360 registers, so the batch goes in sub-batches of 32768
 ])
@@ -242,7 +245,7 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     import ctypes as C
     import torch
 
-    code = COMMON_CODES[code_id]
+    code = COMMON_CODES[code_id] if isinstance(code_id, int) else Code(f"K{code_id[0]}", *code_id)
     pc, table, config = make_table_config(code, decode_type)
     dec = BatchDecoder(table, config)
     lib = _lib.load()
