@@ -1135,7 +1135,8 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     static_assert(SP::NREG == 16 && SP::DW == 1 && SP::SPS == 4 && SP::SB == 6, "K = 7 layout");
     constexpr int SB = SP::SB;
     constexpr int IGN = SB < 8 ? SB : 8;                       // ViterbiTracebackBuffer::get_layout (core.h:129-149)
-    constexpr int SHIFT_STATE = 8 - IGN, SHIFT_TAIL = SB - IGN, TOTAL_BITS = SB + SHIFT_STATE;
+    constexpr int SHIFT_STATE = 8 - IGN;
+    static_assert(SB - IGN == 0, "shift_tail = 0: the output byte is the 8-bit register itself");
     constexpr int NBUF = 8;                                    // even: keeps the byte-output positions compile-time
 
     const int lane = threadIdx.x & 63;
@@ -1153,29 +1154,37 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
     // {row q.byte(h), row q.byte(2+h), row q+1.byte(h), row q+1.byte(2+h)}: frame h's 16+16 bits of two q-rows
     constexpr u32 SELA = 0x06040200u, SELB = 0x07050301u;
 
-    u32 regA = (a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u) << SHIFT_STATE;
-    u32 regB = (a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u) << SHIFT_STATE;
+    // The reference's 8-bit register (state in its top SB bits, core.h:110-113) is the TOP BYTE of a 32-bit shift register here,
+    // and beside it the chase keeps the survivor's SLOT: the update's in-place layout moves no state between slots, so going
+    // back one step replaces exactly one bit of the slot index -- position (SB - (t+1) % SB) % SB -- by the decision bit (a
+    // shift and a bit-field insert where forming the slot from the state took a rotation: 8 instead of 15 instructions per frame
+    // and step; they are what the chainback takes from the update kernel it runs beside)
+    const u32 esA = a.end_state ? (a.end_state[fA] & SP::SMASK) : 0u, esB = a.end_state ? (a.end_state[fB] & SP::SMASK) : 0u;
+    u32 regA = esA << (24 + SHIFT_STATE), regB = esB << (24 + SHIFT_STATE);
+    const u32 ph_top = ((u32)a.L + (u32)SB) % (u32)SB;         // (t + 1) % SB of the first step, t = L - 1 + SB
+    u32 xA = ((esA >> ph_top) | (esA << (SB - ph_top))) & SP::SMASK, xB = ((esB >> ph_top) | (esB << (SB - ph_top))) & SP::SMASK;
 
-    // one traceback step of one frame on the four dwords (one per q-row) that hold step t
-    auto chase1 = [&](u32& reg, u32 lo, u32 hi, u32 ph1) __attribute__((always_inline)) {
-        const u32 state = reg >> SHIFT_STATE;
-        const u32 x = ((state >> ph1) | (state << (SB - ph1))) & SP::SMASK;   // slot of `state` after step t
-        const u32 w = (x & 32u) ? hi : lo;
-        const u32 bit = (w >> (x & 31u)) & 1u;
-        reg = (reg >> 1) | (bit << (TOTAL_BITS - 1));
+    // one traceback step of one frame on the four dwords (one per q-row) that hold step t; steps come in descending order
+    // `p`: the slot bit this step's decision replaces, (SB - (t + 1) % SB) % SB -- wave-uniform, kept on the scalar unit
+    auto chase1 = [&](u32& reg, u32& x, u32 lo, u32 hi, u32 p) __attribute__((always_inline)) {
+        const u32 w = x > 31u ? hi : lo;
+        const u32 bit = __builtin_amdgcn_ubfe(w, x, 1);        // v_bfe_u32 takes the offset's low five bits: x & 31
+        reg = (reg >> 1) | (bit << 31);
+        x = (x & ~(1u << p)) | (bit << p);
     };
-    auto chase = [&](u32 d0, u32 d1, u32 d2, u32 d3, u32 ph1) __attribute__((always_inline)) {
-        chase1(regA, __builtin_amdgcn_perm(d1, d0, SELA), __builtin_amdgcn_perm(d3, d2, SELA), ph1);
-        chase1(regB, __builtin_amdgcn_perm(d1, d0, SELB), __builtin_amdgcn_perm(d3, d2, SELB), ph1);
+    auto chase = [&](u32 d0, u32 d1, u32 d2, u32 d3, u32 p) __attribute__((always_inline)) {
+        chase1(regA, xA, __builtin_amdgcn_perm(d1, d0, SELA), __builtin_amdgcn_perm(d3, d2, SELA), p);
+        chase1(regB, xB, __builtin_amdgcn_perm(d1, d0, SELB), __builtin_amdgcn_perm(d3, d2, SELB), p);
     };
+    auto pos_of = [](int t) __attribute__((always_inline)) -> u32 { return (u32)((SB - (t + 1) % SB) % SB); };
     auto emit = [&](u32 jb) __attribute__((always_inline)) {    // byte jb is complete
-        outA[jb] = (uint8_t)((regA >> SHIFT_TAIL) & 0xFFu);
-        outB[jb] = (uint8_t)((regB >> SHIFT_TAIL) & 0xFFu);
+        outA[jb] = (uint8_t)(regA >> 24);
+        outB[jb] = (uint8_t)(regB >> 24);
     };
     // ragged ends: load the step's dwords directly (dependent latency, only a handful of steps)
     auto slow_step = [&](int t) __attribute__((always_inline)) {
         const u32* r32 = (const u32*)(rows + (size_t)(t >> 2) * 64) + (t & 3);
-        chase(r32[0], r32[16 * 4], r32[32 * 4], r32[48 * 4], (u32)((t + 1) % SB));
+        chase(r32[0], r32[16 * 4], r32[32 * 4], r32[48 * 4], pos_of(t));
         const int j = t - SB;
         if ((j & 7) == 0) emit((u32)j >> 3);
     };
@@ -1192,7 +1201,7 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) buf[b][qq] = rows[(size_t)(g_top - b) * 64 + qq * 16];
         int gb = g_top;
-        u32 ph = (u32)((4 * gb + 3 + 1) % SB);                  // (t+1) % SB of the first step of the ring
+        u32 pos = (u32)__builtin_amdgcn_readfirstlane((int)pos_of(4 * gb + 3));   // of the first step of the ring; +1 (mod SB) per step
         // One inner iteration = NBUF groups = 32 steps = 4 output bytes per frame.  Inside the inner loop ONLY loads are
         // outstanding: with a store pending next to them hipcc must assume out-of-order completion and drains the ring with
         // s_waitcnt vmcnt(0) at every loop top (one full memory round trip per 32 steps -- that, not bandwidth, was the
@@ -1217,18 +1226,18 @@ VIT_DEV void reg_chainback16_body(const RegChainbackArgs& a) {
                         const u32 d1 = sidx == 0 ? buf[b][1].x : sidx == 1 ? buf[b][1].y : sidx == 2 ? buf[b][1].z : buf[b][1].w;
                         const u32 d2 = sidx == 0 ? buf[b][2].x : sidx == 1 ? buf[b][2].y : sidx == 2 ? buf[b][2].z : buf[b][2].w;
                         const u32 d3 = sidx == 0 ? buf[b][3].x : sidx == 1 ? buf[b][3].y : sidx == 2 ? buf[b][3].z : buf[b][3].w;
-                        chase(d0, d1, d2, d3, ph);
-                        ph = ph == 0 ? SB - 1 : ph - 1;
+                        chase(d0, d1, d2, d3, pos);
+                        pos = pos + 1 == (u32)SB ? 0u : pos + 1;
                         // j = 4*grp + sidx - 6 is a multiple of 8  <=>  grp odd and sidx == 2: byte (4*grp - 4) / 8 is
                         // complete; bytes come out in descending order, so the first one ends up in the top byte
                         if ((b & 1) == 1 && sidx == 2) {
-                            accA = (accA << 8) | ((regA >> SHIFT_TAIL) & 0xFFu);
-                            accB = (accB << 8) | ((regB >> SHIFT_TAIL) & 0xFFu);
+                            accA = (accA << 8) | (regA >> 24);
+                            accB = (accB << 8) | (regB >> 24);
                         }
                     }
                     // pin the chase of this group in front of its refill: without a side effect per group the optimiser sinks
                     // the whole dependent chain below all eight refills and parks 128 permuted words in AGPRs / scratch
-                    asm volatile("" : "+v"(regA), "+v"(regB) : : "memory");
+                    asm volatile("" : "+v"(regA), "+v"(regB), "+v"(xA), "+v"(xB) : : "memory");
                     const int nxt = grp - NBUF;
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) { typedef u32 u32x4_t __attribute__((ext_vector_type(4))); const u32x4_t v4 = __builtin_nontemporal_load((const u32x4_t*)&rows[(size_t)(nxt < 0 ? 0 : nxt) * 64 + qq * 16]); buf[b][qq] = make_uint4(v4.x, v4.y, v4.z, v4.w); }
