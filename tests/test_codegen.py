@@ -85,6 +85,10 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
     assert "global_store" not in text and "scratch_" not in text
     waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
     assert waits and all(int(w) > 0 for w in waits), waits
+    # the chase keeps the survivor's slot (one bit replaced per step) and the bit's position on the scalar unit: 8.5 vector
+    # instructions per frame and step -- 543 for the loop's 32 steps of two frames (the rotate-the-state form: ~960)
+    valu = sum(1 for l in lines[a:b] if l.strip().startswith("v_"))
+    assert valu <= 600 and "v_readfirstlane" not in text, valu
 
 
 @pytest.mark.parametrize("reg_id", [3, 4])
