@@ -217,6 +217,35 @@ int vit_hip_pipeline_set_timing(vit_hip_pipeline_t p, int enable);
 int vit_hip_pipeline_get_timing(vit_hip_pipeline_t p, size_t capacity, float* update_ms, float* chainback_ms, float* complete_ms,
                                 size_t* n_batches);
 
+/* Order the NEXT submitted batch behind work of the caller's own stream: its update kernel will not start before `event` (a
+ * hipEvent_t passed as void*, recorded by the caller on the stream that produces d_symbols / last used d_bytes_out) has fired.
+ * The pipeline runs on private non-blocking streams, so without this (or a device / stream synchronisation) a submit() right
+ * after an asynchronous producer of the symbols races with it.  The other direction is submit()'s `done_event`: make the
+ * consumer's stream wait on it.  No reference counterpart (the reference is synchronous host code). */
+int vit_hip_pipeline_wait_event(vit_hip_pipeline_t p, void* event);
+
+/* ---- what the hardware allocates per wave of a kernel (diagnostics; the pipeline's residency rules read the same table) ---- */
+
+/* From the kernel DESCRIPTOR in the code object (compute_pgm_rsrc1/3, group_segment_fixed_size): the numbers the wave launcher
+ * uses to decide which waves share a SIMD / CU.  NOT hipFuncGetAttributes().numRegs, which is the count the code uses: hipcc
+ * pads the allocation of kernels whose static LDS limits their occupancy.  No reference counterpart. */
+typedef struct vit_hip_kernel_resources {
+    uint32_t vgpr_alloc;        /* entries of the SIMD's 512-entry unified register file one wave occupies */
+    uint32_t accum_offset;      /* of which architectural VGPRs (the rest are accumulation registers) */
+    uint32_t lds_static_bytes;  /* per workgroup, fixed at compile time */
+    uint32_t lds_dynamic_bytes; /* per workgroup, added at launch (vit_hip_get_kernel_resources only; 0 from vit_hip_list_kernels) */
+    uint32_t scratch_bytes;     /* per lane */
+} vit_hip_kernel_resources;
+#define VIT_HIP_KERNEL_UPDATE 0
+#define VIT_HIP_KERNEL_CHAINBACK 1
+#define VIT_HIP_KERNEL_CHAINBACK_ALT 2   /* the other chainback kernel of K = 7 / 9 (VIT_HIP_CHAINBACK_ALT=1: tests only) */
+#define VIT_HIP_KERNEL_RESUME 3
+/* the kernel a handle launches for `kernel` (register plan and PLAN_LDS2; VIT_HIP_ERR_UNSUPPORTED for PLAN_LDS) */
+int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out);
+/* every kernel of the library's embedded gfx950 code objects, by index (needs no GPU): VIT_HIP_ERR_INVALID_ARG past the end.
+ * `name` receives the (mangled) kernel name, truncated to name_capacity - 1 characters. */
+int vit_hip_list_kernels(size_t index, char* name, size_t name_capacity, vit_hip_kernel_resources* out);
+
 /* ---- batched streaming: a batch of decoders fed in chunks, state resident on the device ------------------------- */
 
 /* reset(start_state) for every frame: d_metrics [frames][N] error_t <- initial_non_start_error, initial_start_error at the

@@ -121,9 +121,11 @@ public:
     }
 
     void reset(size_t starting_state = 0) {
-        m_pending_steps = 0;                        // queued steps of the frame that is being abandoned are dropped, like its state
-        m_pending_symbols.clear();
-        m_unreported_renormalisation = 0;
+        // The reference has run (and reported the renormalisation of) every step update() was given: queued steps are run before the
+        // state is dropped, and their sum -- like any sum already computed but not yet returned (a frame shorter than the traceback
+        // buffer whose last calls were flushed by get_error() / chainback()) -- stays owed: the next update() returns it, or the
+        // caller collects it with take_unreported_renormalisation().  Never discarded silently.
+        flush_pending();
         m_current_decoded_bit = 0;
         error_t* m = m_metrics.raw_old();
         for (size_t s = 0; s < NUMSTATES; s++) m[s] = m_config.initial_non_start_error;
@@ -151,14 +153,25 @@ public:
     // COMPUTED since the last value it returned: zero while steps are queued, their whole sum from the call that runs them, so
     // the caller's running total (accumulated_error += update(...)) is the reference's whenever the queue is empty -- in
     // particular after the call that completes a frame.
+    //
+    // EXACT mode (set_exact_update_return(true), or compile with -DVITERBI_HIP_EXACT_UPDATE_RETURN): nothing is deferred -- every
+    // update() call runs its steps at once and returns exactly what ViterbiDecoder_Scalar::update returns for that call
+    // (scalar.h:29-56), at one GPU launch (about 25 us) per call.  For callers that use the per-call value itself rather than
+    // its running total.
     static constexpr size_t MAX_PENDING_STEPS = 2048;
     static constexpr size_t MAX_DEFERRED_CALL_STEPS = 64;     // calls longer than this flush the queue and run directly
+
+    void set_exact_update_return(bool exact) {
+        flush_pending();
+        m_exact_update_return = exact;
+    }
+    bool get_exact_update_return() const { return m_exact_update_return; }
 
     void enqueue_steps(const soft_t* symbols, size_t steps) {
         m_pending_symbols.insert(m_pending_symbols.end(), symbols, symbols + steps * R);
         m_pending_steps += steps;
         m_current_decoded_bit += steps;
-        if (m_pending_steps >= MAX_PENDING_STEPS || m_current_decoded_bit >= m_decisions.size()) flush_pending();
+        if (m_exact_update_return || m_pending_steps >= MAX_PENDING_STEPS || m_current_decoded_bit >= m_decisions.size()) flush_pending();
     }
     // runs the queued steps; their renormalisation sum is added to what the next update() call returns
     void flush_pending() {
@@ -172,6 +185,8 @@ public:
         m_pending_symbols.clear();
         m_unreported_renormalisation += renorm;
     }
+    // the renormalisation sum of steps that have been computed but whose sum no update() call has returned yet (deferred mode:
+    // flushes triggered by get_error(), chainback(), reset() or a direct read of the state); collecting it here settles the debt
     uint64_t take_unreported_renormalisation() {
         const uint64_t v = m_unreported_renormalisation;
         m_unreported_renormalisation = 0;
@@ -192,4 +207,9 @@ private:
     std::vector<soft_t> m_pending_symbols;
     size_t m_pending_steps = 0;
     uint64_t m_unreported_renormalisation = 0;
+#ifdef VITERBI_HIP_EXACT_UPDATE_RETURN
+    bool m_exact_update_return = true;
+#else
+    bool m_exact_update_return = false;
+#endif
 };

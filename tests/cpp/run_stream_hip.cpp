@@ -2,7 +2,8 @@
 // trellis step per call (examples/helpers/puncture_code_helpers.h:51, examples/run_punctured_decoder.cpp:165-176), a punctured
 // K=7 R=1/4 stream with erasure symbols.  Checks, against one update() call over the whole stream on a second decoder:
 // the running total of the return values, get_error(), every metric, every decision word, the chainback bytes -- and, mid-stream,
-// that reading the decoder's public state (m_metrics.get_old(), m_decisions[row]) shows the up-to-date values.
+// that reading the decoder's public state (m_metrics.get_old(), m_decisions[row]) shows the up-to-date values.  Then the EXACT
+// mode (set_exact_update_return: per-call return values are the reference's) and a frame shorter than the traceback buffer.
 // Prints the amortised cost of one N = R call.   usage: run_stream_hip [info bits]
 #include <inttypes.h>
 #include <stdio.h>
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
     once.reset();
     const uint64_t acc_once = Decoder::template update<uint64_t>(once, symbols.data(), symbols.size());
     const uint64_t err_once = acc_once + uint64_t(once.get_error());
+    if (acc_once == 0) { printf("FAIL: the test frame never renormalises\n"); return 1; }
     once.chainback(rx_once.data(), total_input_bits);
 
     Core vitdec(branch_table, setup.config);
@@ -80,6 +82,52 @@ int main(int argc, char** argv) {
         ok = ok && acc >= acc_ref;
         acc += Decoder::template update<uint64_t>(vitdec, symbols.data() + (n + 1) * R, (S - n - 1) * R);     // the rest in one call
         ok = ok && acc == acc_once && acc + uint64_t(vitdec.get_error()) == err_once;
+    }
+    // EXACT mode: every call returns the reference's per-call value -- its running total after n calls is what ONE call over the
+    // first n steps returns (checked at 16 prefixes), nothing is ever queued
+    {
+        Core exact(branch_table, setup.config);
+        exact.set_traceback_length(total_input_bits);
+        exact.set_exact_update_return(true);
+        exact.reset();
+        std::vector<uint64_t> prefix(S + 1, 0);
+        for (size_t t = 0; t < S; t++) {
+            prefix[t + 1] = prefix[t] + Decoder::template update<uint64_t>(exact, symbols.data() + t * R, R);
+            ok = ok && exact.pending_steps() == 0;
+        }
+        ok = ok && prefix[S] == acc_once && prefix[S] + uint64_t(exact.get_error()) == err_once;
+        ok = ok && memcmp(exact.m_decisions[0], once.m_decisions[0], S * sizeof(uint64_t)) == 0;
+        Core ref(branch_table, setup.config);
+        ref.set_traceback_length(total_input_bits);
+        for (int k = 1; k <= 16; k++) {
+            const size_t n = 65 + (S - 66) * size_t(k) / 16;                        // > 64 steps: one direct launch
+            ref.reset();
+            ok = ok && Decoder::template update<uint64_t>(ref, symbols.data(), n * R) == prefix[n];
+        }
+        if (!ok) printf("exact-mode check failed\n");
+    }
+    // a frame SHORTER than the traceback buffer, streamed at N = R in the default (deferred) mode: the last calls stay queued, the
+    // flush comes from get_error() -- its sum is owed, not lost: take_unreported_renormalisation() collects it, and if nobody
+    // does, reset() keeps it for the next update() call
+    {
+        Core shorty(branch_table, setup.config);
+        shorty.set_traceback_length(total_input_bits + 777);
+        for (int collect = 0; collect < 2; collect++) {
+            shorty.reset();
+            uint64_t acc = 0;
+            for (size_t t = 0; t < S; t++) acc += Decoder::template update<uint64_t>(shorty, symbols.data() + t * R, R);
+            const uint64_t e = uint64_t(shorty.get_error());                        // runs what is still queued
+            ok = ok && shorty.pending_steps() == 0 && e == uint64_t(once.get_error());
+            if (collect) {
+                acc += shorty.take_unreported_renormalisation();
+                ok = ok && acc == acc_once && acc + e == err_once;
+            } else {
+                shorty.reset();                                                     // the debt survives the reset ...
+                acc += Decoder::template update<uint64_t>(shorty, symbols.data(), R);   // ... and the next call pays it
+                ok = ok && acc == acc_once;
+            }
+        }
+        if (!ok) printf("short-frame check failed\n");
     }
     const size_t errors = count_bit_errors(tx, rx_stream);
     printf("streaming update(N=R): %zu calls, %.3f us per call amortised (%.1f Mbit/s), %zu/%zu incorrect bits, error_metric=%" PRIu64 "\n",

@@ -97,3 +97,56 @@ def test_dab_fic_punctured_batch_front_end(oracle, decode_type):
     ref = np.zeros((F, short.size), dtype=flat.dtype)
     ref[:, short] = src
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("decode_type", ["SOFT16", "HARD8"])
+def test_streaming_exact_return_mode_and_short_frames(oracle, decode_type):
+    """(1) set_exact_update_return(True): every N = R call returns what the reference's update() returns for THAT call
+    (examples/helpers/puncture_code_helpers.h:51 accumulates per call) -- checked call by call against the oracle streamed the
+    same way.  (2) default (deferred) mode with a frame SHORTER than the traceback buffer: the flush comes from get_error(),
+    its renormalisation sum is owed -- collected by take_unreported_renormalisation(), or kept across reset() for the next
+    update(): never dropped (round-3 advisor finding)."""
+    code = COMMON_CODES[4]
+    pc = get_decoding_config(decode_type, code.R)
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    config = ViterbiDecoder_Config.from_decoder_config(pc)
+    L = 2048 if decode_type == "SOFT16" else 256           # long enough to renormalise several times
+    tx, sym = synth.make_frames_numpy(code, pc, 1, L, 2.0, seed=11)
+    flat = sym[0].reshape(-1)
+    S = L + code.K - 1
+    cfg = oracle_cfg(decode_type, code.R)
+    whole = oracle.decode(code.K, code.R, code.G, cfg, flat, L)
+    assert whole["renorm_sum"] > 0
+    # the oracle's per-call values: its update() called with the R symbols of one step at a time
+    otab = oracle.branch_table(code.K, code.R, code.G, cfg.high, cfg.low)
+    om = oracle.reset(code.K, code.R, cfg, 0)
+    per_call = [oracle.update(code.K, code.R, cfg, otab, om, np.ascontiguousarray(flat[t * code.R:(t + 1) * code.R]))[1] for t in range(S)]
+    assert sum(per_call) == whole["renorm_sum"] and max(per_call) > 0
+
+    exact = ViterbiDecoder_Core(table, config)
+    exact.set_traceback_length(L)
+    exact.set_exact_update_return(True)
+    exact.reset()
+    got = []
+    for t in range(S):
+        got.append(ViterbiDecoder_HIP.update(exact, flat[t * code.R:(t + 1) * code.R]))
+        assert exact._pending_steps == 0
+    assert got == per_call                                 # call by call, not only in total
+    assert exact.get_error() == whole["error"]
+    assert np.array_equal(exact.chainback(L), whole["bytes"])
+
+    short = ViterbiDecoder_Core(table, config)
+    short.set_traceback_length(L + 333)
+    for collect in (True, False):
+        short.reset()
+        acc = 0
+        for t in range(S):
+            acc += ViterbiDecoder_HIP.update(short, flat[t * code.R:(t + 1) * code.R])
+        err = short.get_error()                           # runs what was still queued
+        assert err == whole["error"]
+        if collect:
+            acc += short.take_unreported_renormalisation()
+        else:
+            short.reset()
+            acc += ViterbiDecoder_HIP.update(short, flat[:code.R])     # the next call pays the debt
+        assert acc == whole["renorm_sum"]

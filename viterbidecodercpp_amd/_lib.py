@@ -26,6 +26,7 @@ EXPORTS = [
     "vit_hip_reset_batch", "vit_hip_update_batch_resume", "vit_hip_broadcast_table", "vit_hip_synth_batch",
     "vit_hip_count_bit_errors", "vit_hip_shader_clock_mhz", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
     "vit_hip_pipeline_destroy", "vit_hip_pipeline_get_schedule", "vit_hip_pipeline_last_workspace", "vit_hip_pipeline_set_timing", "vit_hip_pipeline_get_timing",
+    "vit_hip_pipeline_wait_event", "vit_hip_get_kernel_resources", "vit_hip_list_kernels",
 ]
 
 
@@ -40,6 +41,14 @@ class VitHipPipelineSchedule(C.Structure):
     _fields_ = [("workspaces", C.c_int32), ("update_streams", C.c_int32), ("chainback_overlapped", C.c_int32),
                 ("chainback_wave_priority", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
                 ("workspace_bytes_each", C.c_size_t), ("sub_batch_frames", C.c_size_t)]
+
+
+class VitHipKernelResources(C.Structure):
+    _fields_ = [("vgpr_alloc", C.c_uint32), ("accum_offset", C.c_uint32), ("lds_static_bytes", C.c_uint32),
+                ("lds_dynamic_bytes", C.c_uint32), ("scratch_bytes", C.c_uint32)]
+
+
+KERNEL_UPDATE, KERNEL_CHAINBACK, KERNEL_CHAINBACK_ALT, KERNEL_RESUME = 0, 1, 2, 3
 
 
 class VitHipError(RuntimeError):
@@ -98,10 +107,30 @@ def load():
     L.vit_hip_pipeline_last_workspace.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     L.vit_hip_pipeline_set_timing.argtypes = [vp, i32]
     L.vit_hip_pipeline_get_timing.argtypes = [vp, sz, vp, vp, vp, C.POINTER(sz)]
+    L.vit_hip_pipeline_wait_event.argtypes = [vp, vp]
+    L.vit_hip_get_kernel_resources.argtypes = [vp, i32, C.POINTER(VitHipKernelResources)]
+    L.vit_hip_list_kernels.argtypes = [sz, C.c_char_p, sz, C.POINTER(VitHipKernelResources)]
     L.vit_hip_update_host.argtypes = [vp, vp, vp, sz, vp, C.POINTER(C.c_uint64)]
     L.vit_hip_chainback_host.argtypes = [vp, vp, sz, sz, vp]
     _lib = L
     return L
+
+
+def _resources_dict(r):
+    return {name: int(getattr(r, name)) for name, _ in VitHipKernelResources._fields_}
+
+
+def list_kernels():
+    """{kernel name: descriptor resources} of every kernel in the library's embedded gfx950 code objects (no GPU needed)"""
+    L = load()
+    out = {}
+    name = C.create_string_buffer(512)
+    r = VitHipKernelResources()
+    i = 0
+    while L.vit_hip_list_kernels(i, name, len(name), C.byref(r)) == OK:
+        out[name.value.decode()] = _resources_dict(r)
+        i += 1
+    return out
 
 
 def check(rc):

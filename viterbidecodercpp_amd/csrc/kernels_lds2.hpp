@@ -37,6 +37,7 @@
 #include <utility>
 
 #include "common.hpp"
+#include "kernel_desc.hpp"
 
 namespace vit {
 
@@ -702,8 +703,40 @@ __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update
 template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) __attribute__((amdgpu_num_vgpr(60)))
 lds2_update_kernel_c120(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
-// codes whose update kernel leaves room for a chainback wave on every SIMD (the pipeline overlaps their chainback)
-inline bool lds2_chainback_fits_beside_update(int K) { return K == 11 || K == 12 || K == 14 || K == 15; }
+// the instantiation lds2_launch_update picks for (K, R): capped kernel or not, compile-time rate or not
+inline bool lds2_update_is_capped(int K) { return K == 11 || K == 14 || K == 15; }
+inline int lds2_update_rt(int K, int R) { return (K == 15 && R == 6) ? 6 : 0; }
+inline size_t lds2_smem_bytes(int K) {
+    const size_t N = (size_t)1 << (K - 1), G = N / 16, GPT = G >= 256 ? 2 : 1;
+    return (size_t)2 * 4 * GPT * 64 * 8 + 32 * 4 + N * 4;                 // Lds2Geom<K>::smem_bytes
+}
+// what one wave of the update / chainback kernel of (K, R) allocates: from the kernel descriptors (kernel_desc.hpp)
+inline bool lds2_kernel_resources(int K, int R, int shift, bool update, kd::KernelResources* out, unsigned* dyn_lds_bytes = nullptr) {
+    if (dyn_lds_bytes) *dyn_lds_bytes = update ? (unsigned)lds2_smem_bytes(K) : 0u;
+    const kd::KernelResources* r = nullptr;
+    if (update) {
+        char inst[64];
+        snprintf(inst, sizeof(inst), "ILi%dELi%dELi%dEEEvNS_14Lds2UpdateArgsE", K, shift ? 8 : 0, lds2_update_rt(K, R));
+        r = kd::find(kd::own_library(), {lds2_update_is_capped(K) ? "23lds2_update_kernel_c120I" : "18lds2_update_kernelI", inst});
+    } else {
+        r = kd::find(kd::own_library(), {"21lds2_chainback_kernelE"});
+    }
+    if (!r) return false;
+    *out = *r;
+    return true;
+}
+// codes whose update kernel leaves room for a chainback wave on every SIMD (the pipeline overlaps their chainback): as many
+// update workgroups as a CU's LDS holds, their waves spread over four SIMDs, plus one chainback wave -- by descriptor allocation.
+// (K = 11, 12, 14, 15 on an MI355X; unreadable descriptors answer "no": back to back)
+inline bool lds2_chainback_fits_beside_update(int K, int R, int shift) {
+    kd::KernelResources u, c;
+    if (!lds2_kernel_resources(K, R, shift, true, &u) || !lds2_kernel_resources(K, R, shift, false, &c)) return false;
+    const size_t threads = (((size_t)1 << (K - 1)) / 16) / ((((size_t)1 << (K - 1)) / 16) >= 256 ? 2 : 1);   // Lds2Geom<K>::T
+    const size_t wg_per_cu = (160 * 1024) / lds2_smem_bytes(K);
+    size_t waves_per_simd = (wg_per_cu * (threads / 64) + 3) / 4;          // what the LDS admits ...
+    if (waves_per_simd > 512 / u.vgpr_alloc) waves_per_simd = 512 / u.vgpr_alloc;   // ... and what the register file does
+    return waves_per_simd * u.vgpr_alloc + c.vgpr_alloc <= 512;
+}
 
 // ---- chainback / export on the PLAN_LDS2 layout -------------------------------------------------------------------
 struct Lds2ChainbackArgs {

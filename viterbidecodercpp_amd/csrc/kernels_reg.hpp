@@ -69,7 +69,13 @@ VIT_DEV u32 pk_max_s(u32 a, u32 b) {
 // price of the asm: the hazard recogniser pads some of its uses with s_nop (2 per step at K = 7)
 VIT_DEV u32 bfi_s(u32 mask, u32 a, u32 b) {
     u32 d;
+#ifdef VIT_REG_BFI_VOP3
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+#else
+    // v_bitop3_b32 with all three operands in VGPRs issues in 2.7 clocks where v_bfi_b32 (and v_bitop3 with a scalar or literal
+    // operand) takes 4.6 (profiles/r4_op_rates.txt): the masks are pinned in vector registers (truth table 0xE4: s2 ? s0 : s1)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(d) : "v"(a), "v"(b), "v"(mask));
+#endif
     return d;
 }
 VIT_DEV u32 pk_min_s(u32 a, u32 b) {
@@ -354,6 +360,12 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // ds_bpermute addresses: the lane with the two lane-group bits swapped (q = 1 <-> q = 2), and the exchange partners
     const u32 LSWADDR = 4u * (u32)((lane & 15) | ((lane & 16) << 1) | ((lane & 32) >> 1));
     const u32 XADDR32 = 4u * (u32)(lane ^ 32), XADDR16 = 4u * (u32)(lane ^ 16);
+    // the bit-field-insert masks of the decision gather, pinned in VECTOR registers (bfi_s): opaque to the optimiser, which would
+    // otherwise fold them back into literals
+    u32 M55 = 0x55555555u, M33 = 0x33333333u, M0F = 0x0F0F0F0Fu;
+#ifndef VIT_REG_BFI_VOP3
+    asm volatile("" : "+v"(M55), "+v"(M33), "+v"(M0F));
+#endif
 
     // the branch pattern contributed by this lane's group q is folded in by exchanging `high` and `low` per polynomial:
     // per-lane constants, one pair per (phase, polynomial)
@@ -648,9 +660,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         P[k] = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 8>{}), dreg(std::integral_constant<int, r>{}), SIGN_BYTES);
                         P[k + 4] = __builtin_amdgcn_perm(dreg(std::integral_constant<int, r + 12>{}), dreg(std::integral_constant<int, r + 4>{}), SIGN_BYTES);
                     });
-                    const u32 q0 = bfi_s(0x55555555u, P[0], P[1]), q1 = bfi_s(0x55555555u, P[2], P[3]);
-                    const u32 q2 = bfi_s(0x55555555u, P[4], P[5]), q3 = bfi_s(0x55555555u, P[6], P[7]);
-                    acc[d] = bfi_s(0x0F0F0F0Fu, bfi_s(0x33333333u, q0, q1), bfi_s(0x33333333u, q2, q3));
+                    const u32 q0 = bfi_s(M55, P[0], P[1]), q1 = bfi_s(M55, P[2], P[3]);
+                    const u32 q2 = bfi_s(M55, P[4], P[5]), q3 = bfi_s(M55, P[6], P[7]);
+                    acc[d] = bfi_s(M0F, bfi_s(M33, q0, q1), bfi_s(M33, q2, q3));
                 };
                 // 64-register codes (K = 9): a 16-register chunk is gathered as soon as its butterflies are done and the
                 // scheduler may not move work across that point -- 64 metrics + 64 live decision values + branch metrics + index
@@ -663,8 +675,14 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     constexpr int r1 = r0 | (1 << PB);
                     constexpr u32 p = SP::pat_reg(PH, (u32)r0);
                     const u32 ma = m[r0], mb = m[r1];
+#ifdef VIT_EXPERIMENT_ADD32
+                    // TIMING EXPERIMENT ONLY (results wrong whenever a low half carries): the ceiling of VOP2 adds
+                    const u32 x0 = ma + E[cur][p], y0 = mb + EB[cur][p];
+                    const u32 x1 = ma + EB[cur][p], y1 = mb + E[cur][p];
+#else
                     const u32 x0 = pk_add(ma, E[cur][p]), y0 = pk_add(mb, EB[cur][p]);   // -> next state (X|0)
                     const u32 x1 = pk_add(ma, EB[cur][p]), y1 = pk_add(mb, E[cur][p]);   // -> next state (X|1)
+#endif
                     m[r0] = pk_min_s(x0, y0);
                     m[r1] = pk_min_s(x1, y1);
                     D[r0] = pk_sub_sat_s(y0, x0);   // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
@@ -964,7 +982,14 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
     while (t >= SB) slow_step(t--);
 }
 
+#ifndef VIT_REG_CB_RING_DEPTH_K7
+#define VIT_REG_CB_RING_DEPTH_K7 4
+#endif
 // ---- lane-local chainback through an LDS ring (K = 7, K = 9): one lane per frame PAIR, 128 frames per wave ----
+// ring slots of four 1 KiB rows + 8 KiB of parked output dwords: 8 slots at K = 9 (40 KiB), 4 at K = 7 (24 KiB: three of these
+// workgroups and the twelve update waves of a three-waves-per-SIMD batch share a CU's 160 KiB)
+constexpr int reg_cb_ring_depth(int nreg) { return nreg == 16 ? VIT_REG_CB_RING_DEPTH_K7 : 8; }
+constexpr unsigned reg_cb_ring_lds_bytes(int nreg) { return (unsigned)reg_cb_ring_depth(nreg) * 4096u + 8192u; }
 // A step's decisions of a tile are 64 lanes x 16 B / SPS and the chase needs ONE bit per frame of them.  Here the rows never
 // touch a register: the wave streams the 1 KiB rows of FOUR tiles into an LDS ring with direct-to-LDS loads
 // (global_load_lds_dwordx4, each row in its own order; counted vmcnt waits), and each lane reads the one BYTE that holds its
@@ -985,13 +1010,19 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
     // ring depth in rows (divides ROWS_IT).  K = 9, beside an update kernel: 4, 8 and 16 rows move the same bytes per second
     // (the chase waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keep update waves off the CU (12.6 ->
     // 14.1 ms per batch)
-    constexpr int D = 8;
+    constexpr int D = reg_cb_ring_depth(SP::NREG);
     static_assert(ROWS_IT % D == 0, "ring slots are compile-time constants");
     constexpr int KI = 16;                                     // iterations between flushes: 64 output bytes per frame
     // the top step of every iteration: t = CT mod 32 (its last decoded bit j = t - SB is a multiple of 32)
     constexpr int CT = (ITER - 1 + SB) % ITER;
-    __shared__ uint4 ring[D * 4 * 64];                         // [slot][tile of the wave][lane of the row]
-    __shared__ u32 obuf[2 * KI * 64];                          // [frame half][iteration][lane]
+    // DYNAMIC LDS (reg_cb_ring_lds_bytes() at launch), on purpose: hipcc pads the register allocation of a kernel whose STATIC LDS
+    // limits its occupancy up to the count that enforces that occupancy (40 KiB per one-wave workgroup = one wave per SIMD =
+    // .amdhsa_next_free_vgpr 257 for the 22 registers this body uses), and a 264-register wave does not fit beside two update
+    // waves.  With the size unknown at compile time the descriptor says what the body needs (tests/test_codegen.py reads it).
+    static_assert(reg_cb_ring_lds_bytes(SP::NREG) == D * 4 * 64 * 16 + 2 * KI * 64 * 4, "launch size of the ring kernels");
+    extern __shared__ uint4 reg_cb_dyn_lds[];
+    uint4* const ring = reg_cb_dyn_lds;                        // [slot][tile of the wave][lane of the row]
+    u32* const obuf = (u32*)(reg_cb_dyn_lds + D * 4 * 64);     // [frame half][iteration][lane]
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef __attribute__((address_space(1))) const void glb_void_t;
     typedef u32 u32_unaligned __attribute__((aligned(1)));
@@ -1416,6 +1447,10 @@ VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
     else if constexpr (SP::NREG == 64) reg_chainback_ring_body<SP>(a);
     else reg_chainback_coop_body<SP>(a);
 }
+// dynamic LDS of a code's chainback kernel (`alt`: of its alternative kernel): the LDS-ring body is K = 9's kernel and K = 7's alternative
+constexpr unsigned reg_chainback_dyn_lds_bytes(int K, bool alt) {
+    return (K == 9 && !alt) ? reg_cb_ring_lds_bytes(64) : (K == 7 && alt) ? reg_cb_ring_lds_bytes(16) : 0u;
+}
 template <class SP>
 constexpr unsigned reg_chainback_frames_per_block() { return (SP::NREG == 16 || SP::NREG == 64) && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
 // (the K = 9 body's LDS ring -- 40 KiB per one-wave workgroup -- allows four of them per CU)
@@ -1451,6 +1486,9 @@ template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 
 #ifndef VIT_REG_JIT_TU
+}  // namespace vit
+#include "kernel_desc.hpp"
+namespace vit {
 // ---- host side ----------------------------------------------------------------------------------------------------
 using Spec_K7R2 = RegSpec<7, 2, 109, 79, 0, 0>;             // Voyager          (common_codes.h:23)
 using Spec_K7R3 = RegSpec<7, 3, 91, 117, 121, 0>;           // LTE              (:24)
@@ -1468,12 +1506,14 @@ struct RegJitModule {
     hipFunction_t chainback = nullptr, export_ = nullptr;
     hipFunction_t chainback_coop = nullptr;         // K = 7, 9: the alternative body (reg_chainback_alt_body)
     unsigned chainback_frames_per_block = 32;
+    kd::Table kernels;                              // kernel descriptors of the module's code object (kernel_desc.hpp)
 };
 
 struct RegCode {
     int id = -1;   // 0..6 in the order above; -1 with jit != nullptr for a run-time compiled code
     int K = 0, R = 0;
     int tile = 32; // frames per wavefront
+    uint32_t G[4] = {0, 0, 0, 0};
     const RegJitModule* jit = nullptr;
 };
 
@@ -1490,7 +1530,11 @@ inline bool reg_code_init(RegCode* rc, int K, int R, const uint32_t* G, const De
         if (table[id].K != K || table[id].R != R) continue;
         bool same = true;
         for (int i = 0; i < R; ++i) same = same && (table[id].G[i] == G[i]);
-        if (same) { rc->id = id; rc->K = K; rc->R = R; rc->tile = K < 7 ? 128 : 32; return true; }
+        if (same) {
+            rc->id = id; rc->K = K; rc->R = R; rc->tile = K < 7 ? 128 : 32;
+            for (int i = 0; i < 4; ++i) rc->G[i] = table[id].G[i];
+            return true;
+        }
     }
     return false;
 }
@@ -1526,8 +1570,6 @@ template <> struct RegSpecOf<6> { using type = Spec_K5R2; };
 template <int ID> int reg_launch_update(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st);
 template <int ID> int reg_launch_chainback(const RegChainbackArgs& a, unsigned tiles, hipStream_t st, bool coop);
 template <int ID> int reg_launch_export(const RegExportArgs& a, unsigned blocks, hipStream_t st);
-// vector registers (arch + accumulation) one wave of the update / chainback kernel holds: what decides which kernels can share a SIMD
-template <int ID> int reg_query_vgprs(int shift, int* update_regs, int* chainback_regs);
 
 #ifdef VIT_REG_ID
 template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a, unsigned tiles, hipStream_t st) {
@@ -1545,25 +1587,14 @@ template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsi
     using SP = RegSpecOf<VIT_REG_ID>::type;
     constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
     if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
-    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), 0, st, a);
+    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, true), st, a);
+    else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, false), st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
     hipLaunchKernelGGL(reg_export_kernel<SP>, dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-template <> int reg_query_vgprs<VIT_REG_ID>(int shift, int* update_regs, int* chainback_regs) {
-    using SP = RegSpecOf<VIT_REG_ID>::type;
-    hipFuncAttributes fu{}, fc{};
-    const hipError_t e1 = shift ? hipFuncGetAttributes(&fu, reinterpret_cast<const void*>(reg_update_kernel<SP, 8>))
-                                : hipFuncGetAttributes(&fu, reinterpret_cast<const void*>(reg_update_kernel<SP, 0>));
-    const hipError_t e2 = hipFuncGetAttributes(&fc, reinterpret_cast<const void*>(reg_chainback_kernel<SP>));
-    if (e1 != hipSuccess || e2 != hipSuccess) return -1;
-    *update_regs = fu.numRegs;
-    *chainback_regs = fc.numRegs;
-    return 0;
 }
 #else
 template <> int reg_launch_update<0>(int, const RegUpdateArgs&, unsigned, hipStream_t);
@@ -1587,44 +1618,61 @@ template <> int reg_launch_export<3>(const RegExportArgs&, unsigned, hipStream_t
 template <> int reg_launch_export<4>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<5>(const RegExportArgs&, unsigned, hipStream_t);
 template <> int reg_launch_export<6>(const RegExportArgs&, unsigned, hipStream_t);
-template <> int reg_query_vgprs<0>(int, int*, int*);
-template <> int reg_query_vgprs<1>(int, int*, int*);
-template <> int reg_query_vgprs<2>(int, int*, int*);
-template <> int reg_query_vgprs<3>(int, int*, int*);
-template <> int reg_query_vgprs<4>(int, int*, int*);
-template <> int reg_query_vgprs<5>(int, int*, int*);
-template <> int reg_query_vgprs<6>(int, int*, int*);
 
-// can two update waves and one chainback wave of this code share a SIMD (512 registers per lane, allocated in granules of 8)?
-// When they cannot (K = 9: two update waves take all 512), the chainback of a batch only runs in the gaps between update
-// kernels, and the pipeline does better feeding the SIMDs half-size sub-batches from two streams.
-inline bool reg_chainback_fits_beside_two_updates(const RegCode& rc, int shift) {
-    int ur = 0, cr = 0, ok = -1;
+// ---- which kernels can share a SIMD: read from the kernel DESCRIPTORS (kernel_desc.hpp), the numbers the wave launcher uses ----
+// (hipFuncGetAttributes().numRegs is the count the code USES; hipcc pads the allocation of kernels whose static LDS limits their
+// occupancy -- round 3's K = 9 chainback used 22 registers and allocated 264)
+enum RegKernelKind { REG_KERNEL_UPDATE = 0, REG_KERNEL_CHAINBACK = 1, REG_KERNEL_CHAINBACK_ALT = 2, REG_KERNEL_RESUME = 3 };
+inline bool reg_kernel_resources(const RegCode& rc, int shift, int kind, kd::KernelResources* out, unsigned* dyn_lds_bytes = nullptr) {
+    if (dyn_lds_bytes) *dyn_lds_bytes = kind == REG_KERNEL_CHAINBACK ? reg_chainback_dyn_lds_bytes(rc.K, false)
+                                      : kind == REG_KERNEL_CHAINBACK_ALT ? reg_chainback_dyn_lds_bytes(rc.K, true) : 0u;
+    const kd::KernelResources* r = nullptr;
     if (rc.jit) {
-        hipFunction_t fu = rc.jit->update[shift ? 1 : 0], fc = rc.jit->chainback;
-        ok = (hipFuncGetAttribute(&ur, HIP_FUNC_ATTRIBUTE_NUM_REGS, fu) == hipSuccess &&
-              hipFuncGetAttribute(&cr, HIP_FUNC_ATTRIBUTE_NUM_REGS, fc) == hipSuccess) ? 0 : -1;
+        const char* name = kind == REG_KERNEL_UPDATE ? (shift ? "vit_jit_update_8" : "vit_jit_update_16")
+                         : kind == REG_KERNEL_RESUME ? (shift ? "vit_jit_resume_8" : "vit_jit_resume_16")
+                         : kind == REG_KERNEL_CHAINBACK ? "vit_jit_chainback" : "vit_jit_chainback_coop";
+        for (const auto& e : rc.jit->kernels)
+            if (e.first == name) r = &e.second;
     } else {
-        switch (rc.id) {
-            case 0: ok = reg_query_vgprs<0>(shift, &ur, &cr); break;
-            case 1: ok = reg_query_vgprs<1>(shift, &ur, &cr); break;
-            case 2: ok = reg_query_vgprs<2>(shift, &ur, &cr); break;
-            case 3: ok = reg_query_vgprs<3>(shift, &ur, &cr); break;
-            case 4: ok = reg_query_vgprs<4>(shift, &ur, &cr); break;
-            case 5: ok = reg_query_vgprs<5>(shift, &ur, &cr); break;
-            case 6: ok = reg_query_vgprs<6>(shift, &ur, &cr); break;
-            default: break;
-        }
+        // Itanium mangling of vit::<kernel><RegSpec<K, R, G0, G1, G2, G3, LANE_BITS>[, SHIFT]>(Args)
+        char spec[96], tail[48];
+        snprintf(spec, sizeof(spec), "7RegSpecILi%dELi%dELj%uELj%uELj%uELj%uELi%dEEE", rc.K, rc.R, rc.G[0], rc.G[1], rc.G[2], rc.G[3],
+                 reg_lane_bits(rc.K));
+        snprintf(tail, sizeof(tail), "ELi%dEEEvNS_13RegUpdateArgsE", shift ? 8 : 0);
+        std::vector<std::string> frag;
+        if (kind == REG_KERNEL_UPDATE) frag = {"17reg_update_kernelI", spec, tail};
+        else if (kind == REG_KERNEL_RESUME) frag = {"17reg_resume_kernelI", spec, tail};
+        else if (kind == REG_KERNEL_CHAINBACK) frag = {"20reg_chainback_kernelI", spec};
+        else frag = {"25reg_chainback_coop_kernelI", spec};
+        r = kd::find(kd::own_library(), frag);
     }
-    if (ok != 0 || ur <= 0 || cr <= 0) return rc.K < 9;          // the runtime would not say: the stock kernels' answer
-    auto alloc = [](int r) { return (r + 7) / 8 * 8; };
-    return 2 * alloc(ur) + alloc(cr) <= 512;
+    if (!r) return false;
+    *out = *r;
+    return true;
 }
 
-inline int reg_jit_launch(hipFunction_t fn, const void* args, size_t args_bytes, unsigned grid, unsigned block, hipStream_t st) {
+constexpr unsigned SIMD_VGPRS = 512, CU_LDS_BYTES = 160 * 1024;
+// can `n_update` update waves and one chainback wave of this code share a SIMD: registers (the descriptors' allocations), and per
+// CU the LDS of 4 n_update update waves plus two chainback workgroups (a 65536-frame batch is 512 of them on 256 CUs)?  When they
+// cannot (K = 9, R = 4: one update wave allocates 360 registers), the chainback of a batch only runs in the gaps between update
+// kernels, and the pipeline does better feeding the SIMDs half-size sub-batches from two streams.  Descriptors that cannot be
+// read (the library file moved away under the process) answer "no": the conservative schedule.
+inline bool reg_chainback_fits_beside_updates(const RegCode& rc, int shift, int n_update, bool alt_chainback = false) {
+    kd::KernelResources u, c;
+    unsigned dyn = 0;
+    if (!reg_kernel_resources(rc, shift, REG_KERNEL_UPDATE, &u) ||
+        !reg_kernel_resources(rc, shift, alt_chainback ? REG_KERNEL_CHAINBACK_ALT : REG_KERNEL_CHAINBACK, &c, &dyn))
+        return false;
+    if ((unsigned)n_update * u.vgpr_alloc + c.vgpr_alloc > SIMD_VGPRS) return false;
+    return 4u * (unsigned)n_update * u.lds_static_bytes + 2u * (c.lds_static_bytes + dyn) <= CU_LDS_BYTES;
+}
+inline bool reg_chainback_fits_beside_two_updates(const RegCode& rc, int shift) { return reg_chainback_fits_beside_updates(rc, shift, 2); }
+
+inline int reg_jit_launch(hipFunction_t fn, const void* args, size_t args_bytes, unsigned grid, unsigned block, hipStream_t st,
+                          unsigned dyn_lds_bytes = 0) {
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &args_bytes,
                       HIP_LAUNCH_PARAM_END};
-    return hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, st, nullptr, config) == hipSuccess ? 0 : -1;
+    return hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, dyn_lds_bytes, st, nullptr, config) == hipSuccess ? 0 : -1;
 }
 
 // steps [first_step, first_step + n_steps) of every frame.  d_metrics_in == null: reset(start_state) (first_step must be 0);
@@ -1665,8 +1713,10 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     }
 }
 
+// `prefer_alt`: launch the code's OTHER chainback kernel (K = 7: the LDS-ring body, 32 registers -- what the pipeline asks for
+// when the chainback shares SIMDs with update waves; K = 9: the cooperative body).  VIT_HIP_CHAINBACK_ALT=0|1 overrides (tests).
 inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
-                         hipStream_t st, unsigned wave_priority = 0) {
+                         hipStream_t st, unsigned wave_priority = 0, bool prefer_alt = false) {
     if (frames == 0 || L == 0) return 0;
     RegChainbackArgs a{};
     a.ws = (const uint4*)d_ws;
@@ -1678,13 +1728,15 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.wave_priority = wave_priority;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     // K = 7, 9: the other chainback kernel of the code (reg_chainback_alt_body) -- tests and experiments only
-    bool coop = false;
+    bool coop = prefer_alt && (rc.K == 9 || rc.K == 7);
     if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';
     if (rc.jit) {
         if (coop && rc.jit->chainback_coop)
-            return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st);
+            return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st,
+                                  reg_chainback_dyn_lds_bytes(rc.K, true));
         const unsigned fpb = rc.jit->chainback_frames_per_block;
-        return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st);
+        return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st,
+                              reg_chainback_dyn_lds_bytes(rc.K, false));
     }
     switch (rc.id) {
         case 0: return reg_launch_chainback<0>(a, tiles, st, coop);

@@ -212,6 +212,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
         return nullptr;
     }
     m->chainback_frames_per_block = (K == 7 || K == 9) ? 128u : lane_bits == 0 ? 64u : 32u;
+    (void)kd::parse_file(hsaco, m->kernels);           // an unreadable table only makes the pipeline pick its conservative schedule
     if ((K == 9 || K == 7) && hipModuleGetFunction(&m->chainback_coop, m->module, "vit_jit_chainback_coop") != hipSuccess) m->chainback_coop = nullptr;
     modules()[mkey] = m;
     return m;

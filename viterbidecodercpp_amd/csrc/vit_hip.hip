@@ -523,7 +523,7 @@ int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t 
 }
 
 static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
-                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority) {
+                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority, bool small_footprint = false) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (frames == 0 || L == 0) return VIT_HIP_OK;
     if (!d_workspace || !d_bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "d_workspace/d_bytes_out is NULL");
@@ -531,7 +531,8 @@ static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (h->plan == VIT_HIP_PLAN_REG) {
-        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority);
+        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority,
+                                          small_footprint && h->K == 7);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
         return VIT_HIP_OK;
     }
@@ -615,10 +616,12 @@ struct vit_hip_pipeline {
     size_t max_frames = 0, L = 0, ws_bytes = 0;
     // schedule (fixed at create time from max_frames): n_ws decision workspaces used round robin, n_upd update streams
     int n_ws = 2, n_upd = 1;
-    void* ws[3] = {nullptr, nullptr, nullptr};
-    hipStream_t s_upd[2] = {nullptr, nullptr}, s_cb = nullptr;
-    hipEvent_t upd_done[3] = {nullptr, nullptr, nullptr}, cb_done[3] = {nullptr, nullptr, nullptr};
-    bool cb_pending[3] = {false, false, false};
+    static constexpr int MAX_UPD = 3, MAX_WS = 4;
+    void* ws[MAX_WS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t s_upd[MAX_UPD] = {nullptr, nullptr, nullptr}, s_cb = nullptr;
+    hipEvent_t upd_done[MAX_WS] = {nullptr, nullptr, nullptr, nullptr}, cb_done[MAX_WS] = {nullptr, nullptr, nullptr, nullptr};
+    bool cb_pending[MAX_WS] = {false, false, false, false};
+    bool cb_small = false;              // K = 7 beside update waves: the 32-register LDS-ring chainback kernel
     unsigned long long n = 0;
     size_t overlap_max_frames = 0;      // largest batch whose chainback is worth running beside the next update
     size_t two_updates_max_frames = 0;  // largest batch that leaves room for a second update kernel beside the first
@@ -676,7 +679,7 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         p->overlap_max_frames = 2 * per_wave;
         p->two_updates_max_frames = per_wave;
         // PLAN_LDS2 codes whose update kernel is capped at 120 registers: the 24-register chainback fits beside four of its waves
-        if (h->plan == VIT_HIP_PLAN_LDS2 && vit::lds2_chainback_fits_beside_update(h->K)) p->overlap_max_frames = (size_t)-1;
+        if (h->plan == VIT_HIP_PLAN_LDS2 && vit::lds2_chainback_fits_beside_update(h->K, h->R, h->shift)) p->overlap_max_frames = (size_t)-1;
         if (const char* o = getenv("VIT_HIP_PIPELINE_OVERLAP")) p->overlap_max_frames = *o == '1' ? (size_t)-1 : *o == '0' ? 0 : p->overlap_max_frames;   // experiments only
         const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
         if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
@@ -695,8 +698,14 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         if (*e == '1' && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames) { p->sub_frames = p->two_updates_max_frames; p->n_upd = 2; }
         if (*e == '0' && p->sub_frames < max_frames) { p->sub_frames = max_frames; p->n_upd = 1; }
     }
+    if (const char* e = getenv("VIT_HIP_PIPELINE_UPDATES")) { if (*e == '3' && p->sub_frames <= p->two_updates_max_frames) p->n_upd = 3; }   // experiments only: three update kernels in flight
     p->n_ws = p->n_upd + 1;
-    if (const char* e = getenv("VIT_HIP_PIPELINE_WS")) { if (*e == '2' || *e == '3') p->n_ws = *e - '0'; }   // experiments only
+    if (const char* e = getenv("VIT_HIP_PIPELINE_WS")) { if (*e >= '2' && *e <= '4') p->n_ws = *e - '0'; }   // experiments only
+    // K = 7, chainback beside update waves: the LDS-ring kernel (32 registers, 24 KiB of LDS) leaves the update waves their
+    // SIMDs -- 1.5 - 2.3 % per batch over the register-ring kernel (160 registers), which stays the kernel of a chainback
+    // that runs alone (it is 7 % faster there)
+    p->cb_small = h->plan == VIT_HIP_PLAN_REG && h->K == 7;
+    if (const char* e = getenv("VIT_HIP_PIPELINE_CB_SMALL")) p->cb_small = *e == '1';   // experiments only
     p->ws_bytes = vit_hip_workspace_bytes(h, p->sub_frames, L);
     p->sym_frame_bytes = (L + (size_t)h->K - 1) * (size_t)h->R * (size_t)h->soft_bytes;
     p->out_frame_bytes = (L + 7) / 8;
@@ -756,7 +765,7 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
             VIT_HIP_CHECK(hipStreamWaitEvent(s_cb, p->upd_done[k], 0));
         }
         if (p->timing) VIT_HIP_CHECK(hipEventRecord(rec.c0, s_cb));
-        rc = chainback_batch_impl(p->h, p->ws[k], nf, p->L, out, es, s_cb, p->cb_wave_priority);
+        rc = chainback_batch_impl(p->h, p->ws[k], nf, p->L, out, es, s_cb, p->cb_wave_priority, p->cb_small && s_cb != s_upd);
         if (rc != VIT_HIP_OK) return rc;
         if (p->timing) {
             VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
@@ -840,13 +849,61 @@ int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedul
     return VIT_HIP_OK;
 }
 
+int vit_hip_pipeline_wait_event(vit_hip_pipeline_t p, void* event) {
+    if (!p || !event) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    DeviceGuard guard(p->h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    // the next batch may go to any update stream (two-update schedules alternate): all of them wait
+    for (int k = 0; k < p->n_upd; ++k) VIT_HIP_CHECK(hipStreamWaitEvent(p->s_upd[k], (hipEvent_t)event, 0));
+    return VIT_HIP_OK;
+}
+
+int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out) {
+    if (!h || !out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    vit::kd::KernelResources r;
+    unsigned dyn = 0;
+    if (h->plan == VIT_HIP_PLAN_REG) {
+        if (kernel < VIT_HIP_KERNEL_UPDATE || kernel > VIT_HIP_KERNEL_RESUME) return fail(VIT_HIP_ERR_INVALID_ARG, "unknown kernel");
+        if (!vit::reg_kernel_resources(h->reg_code, h->shift, kernel, &r, &dyn))
+            return fail(VIT_HIP_ERR_RUNTIME, "kernel descriptor not found in the library's code objects");
+    } else if (h->plan == VIT_HIP_PLAN_LDS2) {
+        if (kernel != VIT_HIP_KERNEL_UPDATE && kernel != VIT_HIP_KERNEL_CHAINBACK) return fail(VIT_HIP_ERR_INVALID_ARG, "unknown kernel");
+        if (!vit::lds2_kernel_resources(h->K, h->R, h->shift, kernel == VIT_HIP_KERNEL_UPDATE, &r, &dyn))
+            return fail(VIT_HIP_ERR_RUNTIME, "kernel descriptor not found in the library's code objects");
+    } else {
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "kernel resources are reported for the register plan and PLAN_LDS2");
+    }
+    out->vgpr_alloc = r.vgpr_alloc; out->accum_offset = r.accum_offset; out->lds_static_bytes = r.lds_static_bytes;
+    out->lds_dynamic_bytes = dyn; out->scratch_bytes = r.scratch_bytes;
+    return VIT_HIP_OK;
+}
+
+int vit_hip_list_kernels(size_t index, char* name, size_t name_capacity, vit_hip_kernel_resources* out) {
+    const vit::kd::Table& t = vit::kd::own_library();
+    if (t.empty()) return fail(VIT_HIP_ERR_RUNTIME, "the library's own file could not be read for its kernel descriptors");
+    if (index >= t.size()) return fail(VIT_HIP_ERR_INVALID_ARG, "index past the last kernel");
+    if (name && name_capacity > 0) {
+        const size_t n = t[index].first.size() < name_capacity - 1 ? t[index].first.size() : name_capacity - 1;
+        memcpy(name, t[index].first.data(), n);
+        name[n] = 0;
+    }
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        const vit::kd::KernelResources& r = t[index].second;
+        out->vgpr_alloc = r.vgpr_alloc; out->accum_offset = r.accum_offset; out->lds_static_bytes = r.lds_static_bytes;
+        out->scratch_bytes = r.scratch_bytes;
+    }
+    return VIT_HIP_OK;
+}
+
 int vit_hip_pipeline_destroy(vit_hip_pipeline_t p) {
     if (!p) return VIT_HIP_OK;
     DeviceGuard guard(p->h->device);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < vit_hip_pipeline::MAX_UPD; ++k)
         if (p->s_upd[k]) (void)hipStreamSynchronize(p->s_upd[k]);
     if (p->s_cb) (void)hipStreamSynchronize(p->s_cb);
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < vit_hip_pipeline::MAX_WS; ++k) {
         if (p->ws[k]) (void)hipFree(p->ws[k]);
         if (p->upd_done[k]) (void)hipEventDestroy(p->upd_done[k]);
         if (p->cb_done[k]) (void)hipEventDestroy(p->cb_done[k]);
@@ -859,7 +916,7 @@ int vit_hip_pipeline_destroy(vit_hip_pipeline_t p) {
     }
     if (p->epoch) (void)hipEventDestroy(p->epoch);
     for (hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < vit_hip_pipeline::MAX_UPD; ++k)
         if (p->s_upd[k]) (void)hipStreamDestroy(p->s_upd[k]);
     if (p->s_cb) (void)hipStreamDestroy(p->s_cb);
     delete p;

@@ -143,6 +143,7 @@ class ViterbiDecoder_Core:
         self._metrics = np.zeros(self.NUMSTATES, dtype=config.error_dtype)
         self._decisions = np.zeros((0, self.TOTAL_BLOCKS), dtype=np.uint64)
         self._pending, self._pending_steps, self._unreported = [], 0, 0
+        self._exact_update_return = False
         self.m_current_decoded_bit = 0
         self.reset()
         self.set_traceback_length(0)
@@ -175,8 +176,16 @@ class ViterbiDecoder_Core:
         assert end_state < self.NUMSTATES
         return int(self.m_metrics[end_state])
 
+    def set_exact_update_return(self, exact: bool):
+        """True: nothing is deferred -- every update() call runs at once and returns what the reference's update() returns for
+        that call (one GPU launch per call); False (default): short calls are queued (see the class docstring)."""
+        self.flush_pending()
+        self._exact_update_return = bool(exact)
+
     def reset(self, starting_state: int = 0):
-        self._pending, self._pending_steps, self._unreported = [], 0, 0     # queued steps of an abandoned frame go with its state
+        # queued steps are run before the state is dropped (the reference has run them and reported their renormalisation); a sum
+        # computed but not yet returned stays owed to the next update() / take_unreported_renormalisation(): never discarded
+        self.flush_pending()
         self.m_current_decoded_bit = 0
         self._metrics[:] = self.m_config.initial_non_start_error
         self._metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
@@ -194,7 +203,7 @@ class ViterbiDecoder_Core:
         self._pending.append(symbols)
         self._pending_steps += steps
         self.m_current_decoded_bit += steps
-        if self._pending_steps >= self.MAX_PENDING_STEPS or self.m_current_decoded_bit >= len(self._decisions):
+        if self._exact_update_return or self._pending_steps >= self.MAX_PENDING_STEPS or self.m_current_decoded_bit >= len(self._decisions):
             self.flush_pending()
 
     def flush_pending(self):
@@ -493,14 +502,36 @@ class DecodePipeline:
             _lib.check(_lib.load().vit_hip_pipeline_create(decoder._handle._h, self.max_frames, self.L, C.byref(self._p)))
         self.schedule = _lib.VitHipPipelineSchedule()
         _lib.check(_lib.load().vit_hip_pipeline_get_schedule(self._p, C.byref(self.schedule)))
+        # the pipeline runs on private non-blocking streams: these two events order it against torch's streams
+        t = decoder.torch
+        with t.cuda.device(decoder.device):
+            self._inputs_ready, self._done = t.cuda.Event(), t.cuda.Event()
+            self._done.record()                                  # materialises the hipEvent_t the pipeline re-records
 
-    def submit(self, symbols, out, end_state=None):
-        """enqueue one batch: symbols [F][L+K-1][R] -> out [F][L/8]; both must stay untouched until sync()"""
+    def submit(self, symbols, out, end_state=None, after_current_stream=True):
+        """enqueue one batch: symbols [F][L+K-1][R] -> out [F][L/8]; both must stay untouched until sync() / wait_done().
+        after_current_stream (default): the batch's update kernel is ordered behind everything already enqueued on torch's
+        current stream of the decoder's device (an event recorded there, vit_hip_pipeline_wait_event), so
+        `sym = dec.synth(...); pipe.submit(sym, out)` needs no synchronisation in between.  False: the caller guarantees the
+        inputs are complete (what a C host without a producer stream does)."""
+        t = self.decoder.torch
         frames = self.decoder._check_symbols(symbols, self.L + self.decoder.K - 1)
-        if out.dtype != self.decoder.torch.uint8 or not out.is_contiguous() or out.numel() != frames * ((self.L + 7) // 8):
+        if out.dtype != t.uint8 or not out.is_contiguous() or out.numel() != frames * ((self.L + 7) // 8):
             raise ValueError("out must be a contiguous uint8 tensor [frames][ceil(L/8)]")
-        _lib.check(_lib.load().vit_hip_pipeline_submit(self._p, C.c_void_p(symbols.data_ptr()), frames, C.c_void_p(out.data_ptr()),
-                                                       C.c_void_p(end_state.data_ptr()) if end_state is not None else None, None))
+        L = _lib.load()
+        if after_current_stream:
+            self._inputs_ready.record(t.cuda.current_stream(self.decoder.device))
+            _lib.check(L.vit_hip_pipeline_wait_event(self._p, C.c_void_p(self._inputs_ready.cuda_event)))
+        _lib.check(L.vit_hip_pipeline_submit(self._p, C.c_void_p(symbols.data_ptr()), frames, C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(end_state.data_ptr()) if end_state is not None else None,
+                                             C.c_void_p(self._done.cuda_event)))
+
+    def wait_done(self, stream=None):
+        """order `stream` (default: torch's current stream) behind every batch submitted so far, without blocking the host:
+        torch work enqueued on it afterwards may read the outputs.  (A later submit(after_current_stream=True) from the same
+        stream is then ordered behind these batches too -- call it only where the outputs are consumed.)"""
+        t = self.decoder.torch
+        (stream or t.cuda.current_stream(self.decoder.device)).wait_event(self._done)
 
     def sync(self):
         _lib.check(_lib.load().vit_hip_pipeline_sync(self._p))
