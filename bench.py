@@ -124,6 +124,45 @@ def launch_ranks(args):
     sys.exit(rc if rc >= 0 else 1)
 
 
+def pin_to_gpu_numa_node(index):
+    """Before any GPU call: restrict this rank's CPU affinity to the CPUs local to ITS GPU (the NUMA node the card hangs off), so
+    that eight ranks of one node do not all queue their launches from socket 0.  GPU `index` is the index-th GPU node of the KFD
+    topology (HIP's order; an integer HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list is honoured); its PCI function's
+    local_cpulist comes from the DRM render node.  Best effort: returns what it did (reported per rank in the JSON line)."""
+    info = {"gpu": index, "numa_node": None, "cpus_local": None, "cpus_used": None, "pinned": False}
+    try:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for n in sorted(int(x) for x in os.listdir(top)):
+            props = {}
+            for line in open(f"{top}/{n}/properties"):
+                kv = line.split()
+                if len(kv) == 2:
+                    props[kv[0]] = kv[1]
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            gpus = [gpus[int(v)] for v in vis.split(",") if int(v) < len(gpus)]
+        minor = gpus[index]["drm_render_minor"]
+        devdir = f"/sys/class/drm/renderD{minor}/device"
+        info["numa_node"] = int(open(f"{devdir}/numa_node").read())
+        local = set()
+        for part in open(f"{devdir}/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                local.update(range(int(a), int(b or a) + 1))
+        info["cpus_local"] = len(local)
+        use = sorted(local & set(os.sched_getaffinity(0)))
+        if use:
+            os.sched_setaffinity(0, use)
+            info["pinned"] = True
+        info["cpus_used"] = len(os.sched_getaffinity(0))
+    except (OSError, ValueError, IndexError, KeyError) as e:
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
 def host_cpu_topology():
     """One logical CPU per PHYSICAL core of ONE socket, restricted to what this process may use (affinity mask and cgroup
     CPU quota).  north_star's comparator is the single-socket AVX2 reference."""
@@ -290,6 +329,7 @@ def main():
                                        dist as vdist, get_decoding_config, pack_blob, synth)
 
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = pin_to_gpu_numa_node(local_rank) if world > 1 else None      # before the first GPU call of this rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -467,11 +507,12 @@ def main():
             return 0, dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
 
     elapsed = elapsed_local
+    step_median_ms = float(np.median(step_times))             # steady state: completion to completion, fill and drain excluded
     per_rank = [float(F) * L * args.steps / elapsed_local / 1e6]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        tmax = torch.tensor([elapsed, step_median_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, step_median_ms = float(tmax[0].item()), float(tmax[1].item())
         rates = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
         dist.all_gather(rates, torch.tensor(per_rank, dtype=torch.float64, device=coll_dev))
         per_rank = [float(r.item()) for r in rates]
@@ -481,12 +522,22 @@ def main():
     bit_errors = int(lut[torch.bitwise_xor(out, tx).long()].sum().item())
     ber = bit_errors / float(F * L)
 
+    # every rank reads its own shader clock under load (untimed extra batches) and says where it was pinned
+    clock_load = clock_under_load() if clock_under_load is not None else (None, None)
+    per_rank_info = None
+    if world > 1:
+        mine = torch.tensor([clock_load[0] or 0.0, float(affinity["numa_node"]) if affinity and affinity["numa_node"] is not None else -1.0,
+                             float(affinity["cpus_used"] or 0) if affinity else 0.0, 1.0 if affinity and affinity["pinned"] else 0.0],
+                            dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros(4, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_info = [{"clock_mhz_under_load": float(t[0].item()), "numa_node": int(t[1].item()), "cpus": int(t[2].item()),
+                          "pinned_to_gpu_local_cpus": bool(t[3].item() > 0)} for t in allr]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    clock_load = clock_under_load() if clock_under_load is not None else (None, None)
     total_bits = float(F) * L * world * args.steps
     value = total_bits / elapsed / 1e6
     step_ms = elapsed / args.steps * 1e3
@@ -511,6 +562,10 @@ def main():
     result = {
         "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
         "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # `value` is wall clock over the K timed steps: it carries the pipeline's fill (the first update has no chainback beside
+        # it) and drain (the last chainback runs alone) and the card's clock ramp.  `value_steady` prices the same batches at the
+        # MEDIAN completion-to-completion step time (max over ranks): what a long stream of batches runs at
+        "value_steady": float(F) * L * world / (step_median_ms * 1e-3) / 1e6,
         "ms_per_step": step_ms, "ms_per_step_min": float(np.min(step_times)), "ms_per_step_median": float(np.median(step_times)),
         "ms_per_step_max": float(np.max(step_times)), "ms_per_step_series": [round(float(x), 3) for x in step_times[:64]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -523,7 +578,8 @@ def main():
                    "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
         "per_gpu_Mbit_s": value / world, "per_rank_Mbit_s": per_rank, "Msym_s": value * code.R,
         "ranks": {"world_size": world, "ranks_in_blob_allreduce": ranks_seen, "backend": args.backend if world > 1 else None,
-                  "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world},
+                  "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world,
+                  "per_rank": per_rank_info},
         "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
         # the clock the SIMDs sustained under a packed-integer load right before / after the timed region (s_memtime against
         # s_memrealtime around ~2 ms of v_pk_add_u16 on every SIMD: vit_hip_shader_clock_mhz), and the nominal maximum
@@ -552,21 +608,21 @@ def main():
     }
     rates = issue_rates()
     if valu_insts and rates:
-        # Two ceilings for the update kernel's vector-instruction rate.  "measured": what a pure stream of packed 16-bit
-        # instructions issues at, timed on the card by wall clock (no clock assumed), with as many waves per SIMD as this batch
-        # gives the update kernel.  "spec": 2 clocks per wave64 instruction at the 2.4 GHz peak clock (the guide's VOP2-class
-        # rate; packed 16-bit forms do not reach it: 4.3 - 4.5 clocks measured).
+        # The ceiling of the update kernel's vector-instruction rate: what a pure stream of packed 16-bit instructions issues
+        # at, timed on the card by wall clock (no clock assumed), with as many waves per SIMD as this batch gives the update
+        # kernel.  (The guide's 2-clock figure is reached by a handful of 32-bit integer opcodes in homogeneous streams only --
+        # profiles/r4_op_rates.txt; with ALL of the kernel's adds in that form it ran 1.5 - 2 % faster, DESIGN.md 4.4 -- so it is
+        # not quoted as a peak any more.)
         ns = rates["packed16_ns_per_wave_instr_per_simd"]
         waves = None
         if dec.plan == _lib.PLAN_REG:
             waves = -(-F_launch // tile_frames) / float(N_SIMD) * NUPD
         wkey = "4" if waves is None else str(int(min(4, max(1, -(-waves // 1)))))
         peak_measured = N_SIMD / ns[wkey]                                  # G wave-instructions per second over the chip
-        peak_spec = N_SIMD * rates["spec_clock_ghz"] / rates["spec_cycles_per_wave64_instr"]
         ach = valu_insts / (upd_ms * 1e-3) / 1e9 * NUPD                    # NUPD launches share the SIMDs while each one runs
         result["roofline_valu"] = {
             "bound": "valu", "kernel": "update", "achieved": ach, "peak": peak_measured, "unit": "G wave-instr/s",
-            "frac": ach / peak_measured, "peak_spec": peak_spec, "frac_of_spec": ach / peak_spec,
+            "frac": ach / peak_measured,
             "valu_insts_per_launch": valu_insts, "launches_in_flight": NUPD,
             "valu_insts_per_state_update_pair": valu_insts * 64.0 / (state_updates / 2.0),
             "update_waves_per_simd": waves, "ns_per_packed_instr_per_simd_at_that_occupancy": ns[wkey],

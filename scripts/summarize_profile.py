@@ -98,7 +98,11 @@ for k in sorted(counters):
     c = {n: sum(v) / len(v) for n, v in counters[k].items()}
     m = meta[k]
     lines += [f"## PMC, per launch: `{k}`", "",
-              f"grid {m['grid']} threads, workgroup {m['wg']}, VGPR {m['vgpr']} (+{m['agpr']} acc), SGPR {m['sgpr']}, "
+              # rocprofv3's VGPR_Count / Accum_VGPR_Count are HALVES of the unified 512-entry register file a wave of this kernel
+              # allocates (K9 update: 120 = 240 / 2).  Printed doubled, which is the number that decides co-residency -- round 3
+              # printed the raw 132 of a chainback kernel thought to hold 22 registers (it allocated 264)
+              f"grid {m['grid']} threads, workgroup {m['wg']}, registers ALLOCATED per wave {2 * (int(m['vgpr']) + int(m['agpr']))} "
+              f"(rocprofv3 VGPR_Count {m['vgpr']} + Accum {m['agpr']}, in halves of the unified file), SGPR {m['sgpr']}, "
               f"LDS {m['lds']} B, scratch {m['scratch']} B", "", "| counter | value per launch |", "|---|---|"]
     for n in sorted(c):
         lines.append(f"| {n} | {c[n]:.6g} |")

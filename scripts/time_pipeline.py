@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""time the decode pipeline (vit_hip_pipeline_*) for ANY code: experiments on schedules (the VIT_HIP_PIPELINE_* switches).
+usage: time_pipeline.py K R G0,G1[,..] decode_type frames L [steps]        (polynomials in decimal or 0o.. octal)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from viterbidecodercpp_amd import BatchDecoder, DecodePipeline, ViterbiBranchTable, ViterbiDecoder_Config, get_decoding_config
+from viterbidecodercpp_amd.codes import Code
+
+K, R = int(sys.argv[1]), int(sys.argv[2])
+G = tuple(int(x, 0) for x in sys.argv[3].split(","))
+dt, F, L = sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+steps = int(sys.argv[7]) if len(sys.argv) > 7 else 12
+code = Code(f"K{K}", K, R, G)
+pc = get_decoding_config(dt, R)
+table = ViterbiBranchTable(K, R, G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+dec = BatchDecoder(table, ViterbiDecoder_Config.from_decoder_config(pc))
+tx, sym = dec.synth(F, L, 3.0, seed=1)
+out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
+pipe = DecodePipeline(dec, F, L)
+s = pipe.schedule
+for _ in range(3):
+    pipe.submit(sym, out)
+pipe.sync()
+pipe.set_timing(True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    pipe.submit(sym, out)
+pipe.sync()
+dtm = (time.perf_counter() - t0) / steps * 1e3
+u, c, d = pipe.timing()
+ber = int(dec.count_bit_errors(out, tx).item()) / float(F * L)
+print(f"K{K} R{R} {dt} {F}x{L}: {dtm:.3f} ms per batch = {F * L / dtm / 1e6:.2f} Gbit/s; update {np.median(u):.3f} chainback {np.median(c):.3f} ms; "
+      f"schedule ws={s.workspaces} upd={s.update_streams} overlapped={s.chainback_overlapped} sub={s.sub_batch_frames}; BER {ber:.2e}")

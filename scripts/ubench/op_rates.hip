@@ -114,6 +114,12 @@ typedef void (*kern_t)(uint64_t*, uint32_t);
 #define M_acs_a32(i)   Q8(A_ADD32) Q8(A_ADD32) Q8(A_MIN) Q8(A_SUB)
 #define M_gat_bfi(i)   Q8(A_PERM) Q8(A_BFI)
 #define M_gat_bit(i)   Q8(A_PERM) Q8(A_BIT)
+#define M_cnd_e64(i)   "v_cndmask_b32_e64 %" #i ", %" #i ", %[c], s[20:21]\n"
+#define M_cmp_cnd(i)   "v_cmp_gt_u32 vcc, %" #i ", %[c]\nv_cndmask_b32 %" #i ", %" #i ", %[d], vcc\n"
+#define M_cmp_cnd_far(i) "v_cndmask_b32 %" #i ", %" #i ", %[d], vcc\n"
+#define M_bfe_i32(i)   "v_bfe_i32 %" #i ", %" #i ", 3, 1\n"
+#define M_pk_ashr(i)   "v_pk_ashrrev_i16 %" #i ", 15, %" #i "\n"
+#define M_swap32(i)    "v_permlane32_swap_b32 %" #i ", %[dd" #i "]\n"
 // mixes: the update step's add / min / sub pattern with the adds in either encoding
 #define M_mix_pk(i)    "v_pk_add_u16 %" #i ", %" #i ", %[c]\nv_pk_add_u16 %" #i ", %" #i ", %[d]\nv_pk_min_i16 %" #i ", %" #i ", %[c]\nv_pk_sub_i16 %" #i ", %" #i ", %[d] clamp\n"
 #define M_mix_a32(i)   "v_add_u32 %" #i ", %" #i ", %[c]\nv_add_u32 %" #i ", %" #i ", %[d]\nv_pk_min_i16 %" #i ", %" #i ", %[c]\nv_pk_sub_i16 %" #i ", %" #i ", %[d] clamp\n"
@@ -128,6 +134,7 @@ typedef void (*kern_t)(uint64_t*, uint32_t);
   X(cmp_u32,"VOPC",1) X(cmp_u16,"VOPC",1) X(cmp_e64,"VOP3 cmp",1) X(add_dpp,"VOP2 DPP",1) X(mov_dpp,"VOP1 DPP",1) X(add_sdwa,"VOP2 SDWA",1) \
   X(bitop3_s,"VOP3 sgpr src",1) X(and_lit,"VOP2 literal src",1) X(and_inl,"VOP2 inline const",1) X(add_inl,"VOP2 inline const",1) \
   X(lshl_v,"VOP2 vgpr shift",1) X(lshr_v,"VOP2 vgpr shift",1) X(pk_add_s,"VOP3P sgpr src",1) X(perm_s,"VOP3 sgpr src",1) \
+  X(cnd_e64,"VOP3 cndmask, sgpr-pair condition",1) X(cmp_cnd,"v_cmp + v_cndmask pairs",2) X(bfe_i32,"VOP3",1) X(pk_ashr,"VOP3P",1) \
   X(mix_pk,"2 pk_add + min + sub, back to back dependent",4) X(mix_a32,"2 add_u32 + min + sub, back to back dependent",4) \
   X(acs_pk,"2 pk_add + min + sub, 8 apart",32) X(acs_a32,"2 add_u32 + min + sub, 8 apart",32) X(gat_bfi,"perm + bfi, 8 apart",16) X(gat_bit,"perm + bitop3, 8 apart",16)
 #define MK(name, cls, n) KERNEL(k_##name, M_##name)

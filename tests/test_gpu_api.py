@@ -230,10 +230,11 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (2, "SOFT16", 2048, 1024, (3, 2, 1)),    # register plan, at most one update wave per SIMD: three workspaces, two updates in flight
     (2, "HARD8", 32768, 256, (3, 2, 1)),     # the largest batch of that schedule on an MI355X (4 x 256 CUs x 32 frames)
     (2, "SOFT16", 40000, 128, (2, 1, 1)),    # up to two update waves per SIMD: chainback beside the next update
-    (2, "SOFT16", 70000, 64, (2, 1, 0)),     # larger: back to back on one stream
+    (2, "SOFT16", 70000, 64, (2, 1, 1)),     # up to THREE update waves per SIMD (K = 7 only: 3 x 152 + the 32 registers of the LDS-ring chainback): still beside
+    (2, "SOFT16", 100000, 64, (2, 1, 0)),    # larger: back to back on one stream
     (7, "SOFT16", 24, 256, (2, 1, 1)),       # K = 15 (PLAN_LDS2, update capped at 120 registers): chainback beside the next update
     ((11, 2, (0o3345, 0o3613)), "SOFT16", 40, 128, (2, 1, 1)),    # K = 11: the same
-    ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 0)),  # K = 13 (139 registers, three waves per SIMD): back to back
+    ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 1)),  # K = 13 (144 registers allocated, three waves per SIMD by LDS: 3 x 144 + 24 of 512): overlapped too -- the descriptor rule; 8192 x 4096: 16.4 -> 16.0 ms per batch
     ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 10 (PLAN_LDS): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9, R = 4: one update wave takes 360 registers, so the batch goes in sub-batches of 32768

@@ -1,0 +1,111 @@
+"""Co-residency, proved on the device rather than read off a compiler remark (the K = 9 chainback "fitted beside two
+update waves" with 22 used registers while its descriptor allocated 264).
+
+tests/cpp/residency_probe.hip fills EVERY SIMD with N one-wave workgroups that allocate exactly what the update kernel's
+descriptor allocates (registers, LDS) and spin on a host-visible flag.  While they spin, the REAL chainback kernel is launched
+through the C ABI on a second stream: it can only complete before the flag is released if its waves fit beside the spinners.
+Negative controls (spinners one register granule too large for the sum to fit 512) must NOT let it through -- that the probe can
+tell the difference is part of the test."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, ViterbiBranchTable, ViterbiDecoder_Config, _lib, get_decoding_config
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Probe:
+    def __init__(self):
+        import torch  # noqa: F401  (one HIP runtime per process: torch's)
+        path = os.path.join(HERE, "cpp", "libresidency_probe.so")
+        assert os.path.exists(path), "tests/cpp/libresidency_probe.so is missing: make -C tests/cpp"
+        self.lib = C.CDLL(path)
+        self.lib.probe_alloc.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.probe_spin.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_uint, C.c_void_p, C.c_double]
+        self.lib.probe_started.argtypes = [C.c_void_p]
+        self.lib.probe_started.restype = C.c_ulonglong
+        self.lib.probe_release.argtypes = [C.c_void_p]
+        self.lib.probe_reset.argtypes = [C.c_void_p]
+        self.lib.probe_free.argtypes = [C.c_void_p]
+        self.sh = C.c_void_p()
+        assert self.lib.probe_alloc(C.byref(self.sh)) == 0
+
+    def close(self):
+        self.lib.probe_free(self.sh)
+
+    def completes_beside(self, spin_vgprs, spin_lds, waves_per_simd, launch_other, other_stream, n_simd, wait_s=1.5):
+        """True iff the work `launch_other()` puts on `other_stream` finishes while waves_per_simd spinners hold every SIMD"""
+        import torch
+        self.lib.probe_reset(self.sh)
+        s_spin = torch.cuda.Stream()
+        blocks = n_simd * waves_per_simd
+        assert self.lib.probe_spin(C.c_void_p(s_spin.cuda_stream), blocks, spin_vgprs, spin_lds, self.sh, 4.0) == 0
+        t0 = time.time()
+        while self.lib.probe_started(self.sh) < blocks and time.time() - t0 < 2.0:
+            time.sleep(0.001)
+        started = self.lib.probe_started(self.sh)
+        try:
+            assert started == blocks, f"only {started} of {blocks} spinner waves became resident: the probe's own premise fails"
+            launch_other()
+            t0 = time.time()
+            done = other_stream.query()
+            while not done and time.time() - t0 < wait_s:
+                time.sleep(0.002)
+                done = other_stream.query()
+        finally:
+            self.lib.probe_release(self.sh)
+            torch.cuda.synchronize()
+        return bool(done)
+
+
+def _decoder(code_index, decode_type="SOFT16"):
+    code = COMMON_CODES[code_index]
+    pc = get_decoding_config(decode_type, code.R)
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    return BatchDecoder(table, ViterbiDecoder_Config.from_decoder_config(pc))
+
+
+def _granule(v):
+    return -(-v // 8) * 8
+
+
+@pytest.mark.parametrize("code_index,waves,alt", [(5, 2, False), (2, 2, False), (2, 2, True), (2, 3, True)])
+def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, alt, monkeypatch):
+    """K = 9: the chainback beside TWO update waves per SIMD (2 x 240 + 24 of 512 registers: the shipped schedule);
+    K = 7: the register-ring chainback beside two (2 x 152 + 160), the LDS-ring kernel beside two and beside THREE (3 x 152 + 32)."""
+    import torch
+
+    dec = _decoder(code_index)
+    upd = dec.kernel_resources(_lib.KERNEL_UPDATE)
+    cb = dec.kernel_resources(_lib.KERNEL_CHAINBACK_ALT if alt else _lib.KERNEL_CHAINBACK)
+    assert waves * upd["vgpr_alloc"] + cb["vgpr_alloc"] <= 512, (upd, cb)          # what the descriptors promise ...
+    monkeypatch.setenv("VIT_HIP_CHAINBACK_ALT", "1" if alt else "0")
+    n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    F, L = 32 * n_simd * 2, 256                                                    # a two-waves-per-SIMD batch, short frames
+    ws = dec.new_workspace(F, L)
+    ws.zero_()
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
+    s_cb = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def launch():
+        with torch.cuda.stream(s_cb):
+            dec.chainback(F, L, out=out, workspace=ws)
+
+    probe = Probe()
+    try:
+        # ... and what the hardware does: spinners with the update kernel's allocation, the real chainback beside them
+        assert probe.completes_beside(upd["vgpr_alloc"], upd["lds_static_bytes"], waves, launch, s_cb, n_simd), \
+            f"the chainback kernel did not run beside {waves} x {upd['vgpr_alloc']}-register waves per SIMD"
+        # negative control: the smallest spinner class whose N waves leave LESS than the chainback's allocation
+        too_big = next(v for v in (120, 128, 152, 160, 168, 176, 240, 248, 256) if waves * v + cb["vgpr_alloc"] > 512)
+        assert not probe.completes_beside(too_big, upd["lds_static_bytes"], waves, launch, s_cb, n_simd, wait_s=0.5), \
+            f"the probe cannot tell: the chainback also ran beside {waves} x {too_big} registers"
+    finally:
+        probe.close()
+    assert int(out.sum().item()) == 0                                             # all-zero decisions chase to all-zero bits

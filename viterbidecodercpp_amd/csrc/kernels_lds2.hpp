@@ -285,7 +285,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // scalar operand -- with both in SGPRs every symbol cost a v_mov first
     // (only the compile-time-rate instantiation has the two registers to spare)
     u32 HIGH2v = HIGH2, LOW2v = LOW2;
-    if constexpr (RT != 0) {
+    if constexpr (false) {      // (round 3: RT != 0; the two registers now hold the decision gather's masks, see M55 / M33 below)
         l2_opaque(HIGH2v);
         l2_opaque(LOW2v);
     }
@@ -301,8 +301,16 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             if (i < R) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
+#ifdef VIT_L2_BUILD_CNDMASK
                 e = l2_add(e, ((ln >> i) & 1) ? a1 : a0);
                 eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
+#else
+                // select by an all-ones / all-zeros mask of the lane's pattern bit (v_bfe_i32 + v_bitop3, 7 clocks) instead of
+                // v_cmp + v_cndmask through VCC (28: profiles/r4_op_rates.txt, v_cndmask_b32 alone issues once per 23 clocks)
+                const u32 mk = (u32)__builtin_amdgcn_sbfe((int)ln, (u32)i, 1u), mkb = (u32)__builtin_amdgcn_sbfe((int)pb, (u32)i, 1u);
+                e = l2_add(e, __builtin_amdgcn_bitop3_b32(a1, a0, mk, 0xE4));
+                eb = l2_add(eb, __builtin_amdgcn_bitop3_b32(a1, a0, mkb, 0xE4));
+#endif
             }
         }
         tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
@@ -426,6 +434,21 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
     u32 mA[16], mB[GPT == 2 ? 16 : 1];
+    // the bit-field-insert masks of the decision gather in VECTOR registers: v_bitop3_b32 with three VGPR operands issues in 2.7
+    // clocks, with a scalar operand in 4.7 (profiles/r4_op_rates.txt); opaque, or the optimiser folds them back into SGPR literals
+    u32 M55 = 0x55555555u, M33 = 0x33333333u, M0F = 0x0F0F0F0Fu;
+    // how many of them: all three where registers allow (K = 12, 13, 16); under the 120-register cap (K = 11, 14, 15) the Cassini
+    // instantiation carries 0x55.. and 0x33.. (six of a gather's seven inserts) in the two registers its table build gives up
+    // (`high` / `low` stay scalar there: a v_mov per symbol on the four building wavefronts) and the others none -- a register
+    // more spills (12 - 28 bytes of scratch, reloads inside the block)
+#ifndef VIT_L2_VECTOR_MASKS
+    constexpr bool CAPPED = K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
+    constexpr int VECTOR_MASKS = CAPPED ? (RT != 0 ? 2 : 0) : 3;
+#else
+    constexpr int VECTOR_MASKS = VIT_L2_VECTOR_MASKS;
+#endif
+    if constexpr (VECTOR_MASKS >= 2) asm volatile("" : "+v"(M55), "+v"(M33));
+    if constexpr (VECTOR_MASKS >= 3) asm volatile("" : "+v"(M0F));
     // one trellis step on the 16 registers of one group: stage C of a block, table entries at addr[h] + tab_off,
     // decisions of the step -> one dword  (scalar.h:113-134)
     auto stage = [&](auto cc, u32 (&m)[16], const u32 (&addr)[8], u32 tab_off, u32* wdst) __attribute__((always_inline)) {
@@ -450,9 +473,9 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             // perms (the accumulate-by-and_or chain took 8): bit h of every byte <- butterfly h
             sg4[h & 3] = sg;
             if constexpr ((h & 3) == 3) {
-                const u32 nib = l2_bfi(0x33333333u, l2_bfi(0x55555555u, sg4[0], sg4[1]), l2_bfi(0x55555555u, sg4[2], sg4[3]));
+                const u32 nib = l2_bfi(M33, l2_bfi(M55, sg4[0], sg4[1]), l2_bfi(M55, sg4[2], sg4[3]));
                 if constexpr (h == 3) lo4 = nib;
-                else lo4 = l2_bfi(0x0F0F0F0Fu, lo4, nib);
+                else lo4 = l2_bfi(M0F, lo4, nib);
                 // four butterflies in flight at a time: the temporaries of eight do not fit beside two groups of metrics
                 if constexpr (GPT == 2) __builtin_amdgcn_sched_barrier(0);
             }

@@ -639,6 +639,8 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 // ---- add-compare-select, in place  (scalar.h:113-134) ----
                 // biased metrics: x > y (unsigned, reference)  <=>  sign of sat_i16(y' - x'); min is the signed min
                 u32 D[NREG];
+                constexpr bool EARLY_TEST = !LP;            // register 0 is final as soon as its butterfly is done
+                uint64_t early_any = 0;
                 // ---- ... and, chunk by chunk, the gather of the 2 x NREG sign bits.  v_perm_b32 selectors 8..11 replicate the
                 //      sign of a 16-bit half over a whole byte, so one perm of the register pair (r, r+8) yields four CLEAN bytes
                 //      (0x00 / 0xFF): {A r, B r, A r+8, B r+8}; pair j then drops into bit j of every byte with a single v_and_or
@@ -687,6 +689,20 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     m[r1] = pk_min_s(x1, y1);
                     D[r0] = pk_sub_sat_s(y0, x0);   // sign set <=> x0 > y0 (strict: tie keeps predecessor 0)
                     D[r1] = pk_sub_sat_s(y1, x1);
+                    // the threshold compare right behind the butterfly that makes state 0 (slot 0 = register 0 of lane group 0), into
+                    // an SGPR pair: the branch at the end of the step then finds its condition long since ready instead of waiting
+                    // for a v_cmp issued in front of it (K7 update alone -1.3 %, hard8 -2.5 %; not in the classic lane phases, whose
+                    // exchange after the butterflies still moves register 0)
+                    if constexpr (EARLY_TEST && r0 == 0) {
+                        if constexpr (NREG >= 64) {
+                            const u32 maskq0 = lane < 16 ? BIAS2 : 0u;
+                            const u32 c = (pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq0;
+                            asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(early_any) : "v"(c));
+                        } else {
+                            const u32 pm = pk_max_s(m[0], TLANE);
+                            asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(early_any) : "v"(pm), "v"(TCMP));
+                        }
+                    }
                     if constexpr (CHUNKED) {
                         if constexpr (PB <= 3) {
                             // the pair bit lies inside a chunk: butterflies 8k .. 8k+7 complete registers 16k .. 16k+15
@@ -769,7 +785,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 //      0, register 0) in every layout ----
                 {
                     bool any;
-                    if constexpr (NREG >= 64) {
+                    if constexpr (EARLY_TEST) {
+                        any = early_any != 0;
+                    } else if constexpr (NREG >= 64) {
                         // 64-register codes (K = 9) have no register to spare for a second per-lane constant: three instructions of 356
                         const u32 maskq0 = lane < 16 ? BIAS2 : 0u;
                         any = __builtin_amdgcn_ballot_w64(((pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq0) != 0) != 0;
@@ -1436,8 +1454,10 @@ constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 
 #endif
 template <class SP, int SHIFT>
 __global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, false>(a); }
+// the resumed update (batched streaming) carries the mid-block entry on top of the throughput kernel's registers: one wave per SIMD
+// is promised, so that no instantiation spills (at two, K = 7 R = 3, 4 took 56 - 168 bytes of scratch per lane and K = 9 R = 2 eight)
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) reg_resume_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, true>(a); }
+__global__ void __launch_bounds__(64, 1) reg_resume_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, true>(a); }
 
 // chainback: one kernel name per code, the body is picked by the code's geometry
 template <class SP>

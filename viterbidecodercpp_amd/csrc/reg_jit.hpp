@@ -183,8 +183,8 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
             f << ", " << lane_bits << ">;\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, false>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, false>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_min_waves<SP>()) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
             if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_coop(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";

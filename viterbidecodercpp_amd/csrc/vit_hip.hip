@@ -678,6 +678,9 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         const size_t per_wave = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
         p->overlap_max_frames = 2 * per_wave;
         p->two_updates_max_frames = per_wave;
+        // THREE update waves per SIMD and a chainback wave beside them: only with the K = 7 LDS-ring chainback kernel (3 x 152 + 32
+        // of 512 registers by the kernel descriptors; 98304 x 8192: 161 Gbit/s overlapped against 139 back to back)
+        if (per_wave > 0 && h->K == 7 && vit::reg_chainback_fits_beside_updates(h->reg_code, h->shift, 3, true)) p->overlap_max_frames = 3 * per_wave;
         // PLAN_LDS2 codes whose update kernel is capped at 120 registers: the 24-register chainback fits beside four of its waves
         if (h->plan == VIT_HIP_PLAN_LDS2 && vit::lds2_chainback_fits_beside_update(h->K, h->R, h->shift)) p->overlap_max_frames = (size_t)-1;
         if (const char* o = getenv("VIT_HIP_PIPELINE_OVERLAP")) p->overlap_max_frames = *o == '1' ? (size_t)-1 : *o == '0' ? 0 : p->overlap_max_frames;   // experiments only
@@ -690,7 +693,7 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     p->sub_frames = max_frames;
     p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
     if (h->plan == VIT_HIP_PLAN_REG && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames &&
-        !vit::reg_chainback_fits_beside_two_updates(h->reg_code, h->shift)) {
+        !vit::reg_chainback_fits_beside_updates(h->reg_code, h->shift, 2, /* K = 7: the LDS-ring kernel is the one that runs there */ h->K == 7)) {
         p->sub_frames = p->two_updates_max_frames;
         p->n_upd = 2;
     }
@@ -701,10 +704,11 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     if (const char* e = getenv("VIT_HIP_PIPELINE_UPDATES")) { if (*e == '3' && p->sub_frames <= p->two_updates_max_frames) p->n_upd = 3; }   // experiments only: three update kernels in flight
     p->n_ws = p->n_upd + 1;
     if (const char* e = getenv("VIT_HIP_PIPELINE_WS")) { if (*e >= '2' && *e <= '4') p->n_ws = *e - '0'; }   // experiments only
-    // K = 7, chainback beside update waves: the LDS-ring kernel (32 registers, 24 KiB of LDS) leaves the update waves their
-    // SIMDs -- 1.5 - 2.3 % per batch over the register-ring kernel (160 registers), which stays the kernel of a chainback
-    // that runs alone (it is 7 % faster there)
-    p->cb_small = h->plan == VIT_HIP_PLAN_REG && h->K == 7;
+    // K = 7, chainback beside the update waves of ONE update kernel: the LDS-ring kernel (32 registers, 24 KiB of LDS) leaves
+    // the update waves their SIMDs -- 65536 x 8192: 157 -> 160 Gbit/s over the register-ring kernel (160 registers), which stays
+    // the kernel of a chainback that runs alone (7 % faster there) and of the two-update schedule (there it runs at the higher wave
+    // priority and has to be FAST, not small: hard8 32768 x 8192 163 against 145 Gbit/s)
+    p->cb_small = h->plan == VIT_HIP_PLAN_REG && h->K == 7 && p->n_upd == 1;
     if (const char* e = getenv("VIT_HIP_PIPELINE_CB_SMALL")) p->cb_small = *e == '1';   // experiments only
     p->ws_bytes = vit_hip_workspace_bytes(h, p->sub_frames, L);
     p->sym_frame_bytes = (L + (size_t)h->K - 1) * (size_t)h->R * (size_t)h->soft_bytes;
@@ -744,6 +748,16 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
         const int k = (int)(p->n % (unsigned long long)p->n_ws);
         hipStream_t s_upd = p->s_upd[(int)(p->n % (unsigned long long)p->n_upd)];
         vit_hip_pipeline::Rec rec{nullptr, nullptr, nullptr, nullptr};
+        // the four timing events go back to the pool on every early exit (an error below leaves the sub-batches already
+        // enqueued in flight: the caller syncs -- or destroys -- the pipeline before touching the buffers again)
+        struct RecGuard {
+            vit_hip_pipeline* p; vit_hip_pipeline::Rec* r; bool armed = true;
+            ~RecGuard() {
+                if (!armed) return;
+                for (hipEvent_t e : {r->u0, r->u1, r->c0, r->c1})
+                    if (e && e != p->epoch) p->event_pool.push_back(e);
+            }
+        } rec_guard{p, &rec};
         if (p->timing) {
             rec.u0 = pipe_event(p); rec.u1 = pipe_event(p); rec.c0 = pipe_event(p); rec.c1 = pipe_event(p);
             if (!rec.u0 || !rec.u1 || !rec.c0 || !rec.c1) return fail(VIT_HIP_ERR_RUNTIME, "hipEventCreate failed");
@@ -771,6 +785,7 @@ static int vit_hip_pipeline_submit_impl(vit_hip_pipeline_t p, const void* d_symb
             VIT_HIP_CHECK(hipEventRecord(rec.c1, s_cb));
             p->pending_recs.push_back(rec);
         }
+        rec_guard.armed = false;
         VIT_HIP_CHECK(hipEventRecord(p->cb_done[k], s_cb));
         if (done_event && last) VIT_HIP_CHECK(hipEventRecord((hipEvent_t)done_event, s_cb));
         p->cb_pending[k] = true;
@@ -958,10 +973,13 @@ const RcclApi* rccl_api() {
 
 static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
                             void* branch_table, void* config, int device, vit_hip_stream_t stream) {
-    // Everything that can fail locally runs BEFORE the collective and depends only on arguments every rank passes alike (K, R,
-    // widths, pointers being non-NULL), so a bad call fails on all ranks the same way and nobody is left waiting in
-    // ncclBroadcast.  Once past that point every rank enters the collective exactly once: a root that cannot fill the buffer
-    // broadcasts a poisoned header, which the other ranks report as an error.
+    // Argument checks depend only on what every rank passes alike (K, R, widths, pointers being non-NULL): a bad call fails on
+    // all ranks the same way and nobody is left waiting in ncclBroadcast.  Past them, a rank enters the collective exactly once
+    // whatever happens to its DATA: a root that cannot pack or upload its table broadcasts a poisoned header, which the other
+    // ranks report as an error.  What a rank cannot do is take part without a device or a device buffer: hipSetDevice /
+    // hipMalloc(<= 96 KiB) failing on ONE rank returns VIT_HIP_ERR_NO_DEVICE from that rank BEFORE the collective, and the other
+    // ranks wait in ncclBroadcast until the caller aborts the communicator (ncclCommAbort) -- the usual contract of a rank that
+    // dies in front of a collective; include/vit_hip.h says so.
     if (!nccl_comm || !branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     if (K < 2 || K > 16 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
         return fail(VIT_HIP_ERR_UNSUPPORTED, "unsupported (K, R, soft_t, error_t)");
@@ -970,10 +988,12 @@ static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int
     if (!api) return fail(VIT_HIP_ERR_RUNTIME, "RCCL not available: ncclBroadcast is neither in the process nor in librccl.so");
     std::vector<uint8_t> blob(need, 0);
     DeviceGuard guard(device);
-    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    if (!guard.ok)
+        return fail(VIT_HIP_ERR_NO_DEVICE, "hipSetDevice failed on this rank BEFORE the broadcast: abort the communicator, the other ranks are waiting in it");
     hipStream_t st = (hipStream_t)stream;
     void* d_buf = nullptr;
-    VIT_HIP_CHECK(hipMalloc(&d_buf, need));
+    if (hipMalloc(&d_buf, need) != hipSuccess)
+        return fail(VIT_HIP_ERR_NO_DEVICE, "hipMalloc failed on this rank BEFORE the broadcast: abort the communicator, the other ranks are waiting in it");
     std::string root_error;
     if (rank == root) {
         if (vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need) != VIT_HIP_OK) {
@@ -982,7 +1002,8 @@ static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int
         }
         if (hipMemcpyAsync(d_buf, blob.data(), need, hipMemcpyHostToDevice, st) != hipSuccess) {
             root_error = "hipMemcpyAsync (blob to device) failed";
-            (void)hipMemsetAsync(d_buf, 0, sizeof(BlobHeader), st);
+            (void)hipGetLastError();
+            (void)hipMemset(d_buf, 0, sizeof(BlobHeader));       // poison through the null stream, not the one that just failed
         }
     }
     int result = VIT_HIP_OK;

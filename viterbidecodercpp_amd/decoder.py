@@ -297,6 +297,13 @@ class BatchDecoder:
         assert self._ws.data_ptr() % 256 == 0
         return self._ws
 
+    def kernel_resources(self, kernel: int = 0) -> dict:
+        """what one wave / workgroup of this decoder's kernel allocates, from its kernel descriptor (vit_hip_get_kernel_resources;
+        kernel: _lib.KERNEL_UPDATE / _CHAINBACK / _CHAINBACK_ALT / _RESUME)"""
+        r = _lib.VitHipKernelResources()
+        _lib.check(_lib.load().vit_hip_get_kernel_resources(self._handle._h, int(kernel), C.byref(r)))
+        return _lib._resources_dict(r)
+
     def new_workspace(self, frames: int, L: int):
         """a private decision workspace (for double-buffered pipelines: update of batch i+1 beside chainback of batch i)."""
         return self.torch.empty(self.workspace_bytes(frames, L), dtype=self.torch.uint8, device=self.device)
