@@ -166,25 +166,31 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  * idle.  A pipeline owns the decision workspaces and HIP streams of a stream of batches and schedules them (this is what
  * bench.py times).  submit() only enqueues and returns; batches complete in submit order; the caller's symbol and output
  * buffers of a batch must stay untouched until a later sync() (or until `done_event`, an optional hipEvent_t passed as
- * void*, has fired).  The schedule is fixed at create time from max_frames (vit_hip_pipeline_get_schedule reports it):
+ * void*, has fired).  The schedule is fixed at create time from max_frames (vit_hip_pipeline_get_schedule reports it).  Which
+ * kernels may share a SIMD is decided from their kernel DESCRIPTORS (vit_hip_get_kernel_resources: the register allocation the
+ * wave launcher uses, not the count the code touches), 512 registers and 160 KiB of LDS per SIMD / CU:
  *   - register plan, more than one and at most two update waves per SIMD (4 x CUs x workspace_tile_frames < max_frames <=
- *     2 x that: 65536 frames at K = 7, 9 on an MI355X): two workspaces, the chainback of batch i on a second, high-priority
- *     stream beside the update of batch i+1 (K = 7 soft16: 4.15 -> 3.46 ms per 65536-frame batch);
+ *     2 x that: 65536 frames at K = 7, 9 on an MI355X) whose chainback kernel fits beside two update waves: two workspaces,
+ *     the chainback of batch i on a second, high-priority stream beside the update of batch i+1.
+ *       K = 7 (2 x 152 registers): the chainback kernel of this schedule is the LDS-ring one (32 registers, 24 KiB of LDS; the
+ *         register-ring kernel, 160 registers, stays the kernel of a chainback that runs alone): 65536 x 8192 back to back
+ *         4.15 ms per batch -> 3.30 - 3.45 beside the register-ring kernel -> 3.27 - 3.40;
+ *         up to THREE update waves per SIMD (3 x 152 + 32): a 98304-frame batch 5.8 -> 5.0 ms;
+ *       K = 9, R = 2 (update capped at 240 registers, LDS-streaming chainback 24 registers with its ring in DYNAMIC LDS -- as
+ *         static LDS hipcc padded its allocation to 264 and it ran alone on its SIMD): 65536 x 8192 12.8 -> 12.1 ms;
  *   - register plan, at most ONE update wave per SIMD (max_frames <= 4 x CUs x workspace_tile_frames: the 32768-frame share
  *     of an 8-GPU run): THREE workspaces and TWO update streams, so that two update kernels share the SIMDs (a lone wave
- *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream;
- *     (and the chainback kernel at a higher wave priority than the updates: between two staggered update kernels it would
- *     otherwise get the issue slots both leave over and become the bottleneck);
- *     (K = 9, R = 2 as well: its update kernel is capped at 240 registers and its chainback streams the decision rows
- *     through LDS in 24, so two update waves and a chainback wave share a SIMD: 65536 frames 13.3 -> 12.4-13.0 ms per batch);
- *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9, R = 4: 360
- *     registers per wave): a batch of up to two waves per SIMD is fed to the kernels as SUB-BATCHES of one wave per SIMD
- *     through the same three-workspace, two-update-stream schedule;
- *   - PLAN_LDS2 at K = 11, 12, 14, 15: the update kernel is capped at 120 registers, which leaves the chainback kernel's 24
- *     on every SIMD beside four update waves: two workspaces, chainback beside the next update (K = 15, 4096 frames:
- *     51.6 -> 50.2 ms per batch);
- *   - larger register-plan batches, K = 13, 16 and PLAN_LDS fill the CUs by themselves, a chainback in their way costs more
- *     than it hides: one stream, update and chainback back to back. */
+ *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream, at a
+ *     higher wave priority than the updates (between two staggered update kernels the chainback would otherwise get the issue
+ *     slots both leave over and become the bottleneck; here the fast register-ring kernel serves K = 7 too);
+ *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9, R = 4: 368
+ *     registers per wave; K = 7, R = 3: 2 x 248 + 32 > 512): a batch of up to two waves per SIMD is fed to the kernels as
+ *     SUB-BATCHES of one wave per SIMD through the same three-workspace, two-update-stream schedule;
+ *   - PLAN_LDS2 where the update waves a CU's LDS admits leave the chainback kernel's 24 registers on every SIMD (K = 11, 12,
+ *     14, 15: four waves of at most 120; K = 13: three of 144): two workspaces, chainback beside the next update (K = 15,
+ *     4096 frames: 51.6 -> 50.2 ms per batch; K = 13, 8192 x 4096: 16.4 -> 16.0);
+ *   - larger register-plan batches, K = 16 (4 x 128 registers fill the SIMDs) and PLAN_LDS: a chainback in the update's way
+ *     costs more than it hides: one stream, update and chainback back to back. */
 typedef struct vit_hip_pipeline* vit_hip_pipeline_t;
 typedef struct vit_hip_pipeline_schedule {
     int32_t workspaces;             /* decision workspaces owned (2 or 3) */
@@ -196,6 +202,8 @@ typedef struct vit_hip_pipeline_schedule {
     size_t workspace_bytes_each;
     size_t sub_batch_frames;        /* a submitted batch reaches the kernels in sub-batches of at most this many frames
                                        (= max_frames unless the schedule splits); timing records are per sub-batch */
+    int32_t chainback_small_kernel; /* 1: overlapped chainbacks run the small-footprint kernel of the code (K = 7: LDS ring, 32 registers) */
+    int32_t reserved;
 } vit_hip_pipeline_schedule;
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,

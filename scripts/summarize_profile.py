@@ -21,7 +21,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-KERNELS = ("reg_update_kernel", "reg_chainback_kernel", "reg_export_kernel", "lds_update_kernel", "lds_chainback_kernel")
+KERNELS = ("reg_update_kernel", "reg_chainback_kernel", "reg_chainback_alt_kernel", "reg_export_kernel", "lds_update_kernel", "lds_chainback_kernel")
 
 
 def short(name):
@@ -137,7 +137,7 @@ if key and traffic:
     tpath = os.path.join(dst, "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
     upd = [k for k in traffic if "update_kernel" in k]
-    cb = [k for k in traffic if "chainback_kernel" in k]
+    cb = [k for k in traffic if "chainback_kernel" in k or "chainback_alt_kernel" in k]
     def valu(k):
         v = counters[k].get("SQ_INSTS_VALU")
         return sum(v) / len(v) if v else None

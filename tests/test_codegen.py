@@ -78,7 +78,7 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
         assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         assert 2 * alloc(usage[k]) + alloc(usage[cb[0]]) <= 512, (k, usage[k], usage[cb[0]])
     # the other K = 7 chainback kernel (the LDS-ring body, dynamic LDS): small enough for THREE update waves beside it
-    alt = [k for k in usage if "reg_chainback_coop_kernel" in k]
+    alt = [k for k in usage if "reg_chainback_alt_kernel" in k]
     assert len(alt) == 1 and usage[alt[0]]["lds_static"] == 0
     for k in upd:
         assert 3 * alloc(usage[k]) + alloc(usage[alt[0]]) <= 512, (k, usage[k], usage[alt[0]])
@@ -156,7 +156,7 @@ def test_k9_chainback_streams_rows_through_lds_and_fits_beside_two_update_waves(
     # one counted wait per step (hipcc drops the few that an earlier wait already implies); a drain only where the flush is
     assert waits.count("28") >= 24 and waits.count("0") <= 1 and set(waits) <= {"0", "28"}, waits
     # the alternative (cooperative) kernel keeps its own budget
-    coop = [k for k in usage if "reg_chainback_coop_kernel" in k]
+    coop = [k for k in usage if "reg_chainback_alt_kernel" in k]
     assert len(coop) == 1 and usage[coop[0]]["ScratchSize"] == 0
 
 

@@ -302,6 +302,42 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK
 
 
+def test_decode_pipeline_orders_itself_against_torch_streams():
+    """DecodePipeline runs on private non-blocking streams (round-3 advisor: a data race for `sym = synth(...); submit(sym)`).
+    submit() now orders each batch behind torch's current stream (vit_hip_pipeline_wait_event) and wait_done() orders the current
+    stream behind the pipeline: producer -> pipeline -> consumer with NO host synchronisation in between, on a side stream, with a
+    deliberately slow producer in front (a big matmul), must give the serial decode's bytes."""
+    import torch
+    from viterbidecodercpp_amd import DecodePipeline
+
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    F, L = 40000, 256
+    pipe = DecodePipeline(dec, F, L)
+    assert pipe.schedule.chainback_overlapped == 1 and pipe.schedule.chainback_small_kernel == 1
+    outs, xors = [], []
+    a = torch.randn((6144, 6144), device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for k in range(4):
+            b = a @ a                                           # tens of milliseconds in front of the producer
+            tx, sym = dec.synth(F, L, 2.0, seed=900 + k)        # asynchronous, on `side`
+            out = torch.full((F, L // 8), 0xA5, dtype=torch.uint8, device="cuda")
+            pipe.submit(sym, out)                               # no synchronisation: ordered behind `side` by an event
+            pipe.wait_done()                                    # `side` now waits for this batch ...
+            xors.append(torch.bitwise_xor(out, tx).sum())       # ... so this consumer reads finished bytes
+            outs.append((sym, out, tx))
+            del b
+    torch.cuda.synchronize()
+    for (sym, out, tx), x in zip(outs, xors):
+        ref = dec.decode(sym, L)
+        assert torch.equal(out, ref)                                                       # the pipeline saw the finished symbols
+        assert int(x.item()) == int(torch.bitwise_xor(ref, tx).sum().item())              # the consumer saw the finished bytes
+    pipe.close()
+
+
 def test_shader_clock_measurement():
     import ctypes as C
 

@@ -40,7 +40,8 @@ class VitHipInfo(C.Structure):
 class VitHipPipelineSchedule(C.Structure):
     _fields_ = [("workspaces", C.c_int32), ("update_streams", C.c_int32), ("chainback_overlapped", C.c_int32),
                 ("chainback_wave_priority", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
-                ("workspace_bytes_each", C.c_size_t), ("sub_batch_frames", C.c_size_t)]
+                ("workspace_bytes_each", C.c_size_t), ("sub_batch_frames", C.c_size_t),
+                ("chainback_small_kernel", C.c_int32), ("reserved", C.c_int32)]
 
 
 class VitHipKernelResources(C.Structure):

@@ -1483,16 +1483,16 @@ __global__ void __launch_bounds__(64, reg_chainback_min_waves<SP>()) reg_chainba
     if (a.wave_priority) __builtin_amdgcn_s_setprio(3);
     reg_chainback_body<SP>(a);
 }
-// The body reg_chainback_kernel does NOT run, as a kernel of its own (128 / 32 frames per block as the bodies say).  Selected
-// with VIT_HIP_CHAINBACK_ALT=1: tests and experiments only.
+// The body reg_chainback_kernel does NOT run, as a kernel of its own (128 / 32 frames per block as the bodies say).
+//  K = 7: the LDS-ring body (32 registers, 24 KiB of dynamic LDS).  Alone it is slower than the register ring (an LDS round trip on
+//         the dependent chain: 0.86 / 0.71 / 0.68 ms against 0.80 / 0.52 / 0.49 at 65536 / 32768 / 8192 frames), but it is the
+//         better neighbour of update waves: the pipeline launches it for chainbacks that run beside the next update of the
+//         one-update schedule (65536 x 8192: 157 -> 160 Gbit/s; three update waves + this kernel fit a SIMD, 3 x 152 + 32) -- NOT
+//         for the two-update schedule, whose chainback runs at the higher wave priority and has to be fast (hard8 32768 x 8192: 145
+//         against 163 Gbit/s);
 //  K = 9: the cooperative body (one wave per 32 frames; every q-lane repeats the chase and a ds_bpermute picks the owner's bit:
-//         34 vector instructions per step for 32 frames, 92 registers).  Level with the ring body alone on the device (8192 /
-//         32768 / 65536 frames x 8192 bits: 0.79 / 1.50 / 2.96 ms against 0.76 / 1.52 / 2.9 - 3.0), no use beside two update
-//         waves (registers, issue slots);
-//  K = 7: the LDS-ring body -- measured and NOT used: with an LDS round trip on the dependent chain it is slower than the
-//         register ring alone (0.82 / 0.65 / 0.63 ms against 0.80 / 0.52 / 0.49 at 65536 / 32768 / 8192 frames) and far slower
-//         beside update waves (65536 x 8192 through the pipeline 115 - 123 against 150 - 154 Gbit/s; three update streams of
-//         32768-frame sub-batches, which its 28 registers would allow: 109 against 144).
+//         34 vector instructions per step for 32 frames, 136 registers allocated).  Level with the ring body alone on the device,
+//         no use beside two update waves; tests only (VIT_HIP_CHAINBACK_ALT=1).
 template <class SP>
 VIT_DEV void reg_chainback_alt_body(const RegChainbackArgs& a) {
     if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);                              // 32 frames per wave
@@ -1501,7 +1501,7 @@ VIT_DEV void reg_chainback_alt_body(const RegChainbackArgs& a) {
 template <class SP>
 constexpr int reg_chainback_alt_min_waves() { return SP::NREG == 16 ? 1 : 2; }
 template <class SP>
-__global__ void __launch_bounds__(64, reg_chainback_alt_min_waves<SP>()) reg_chainback_coop_kernel(RegChainbackArgs a) { reg_chainback_alt_body<SP>(a); }
+__global__ void __launch_bounds__(64, reg_chainback_alt_min_waves<SP>()) reg_chainback_alt_kernel(RegChainbackArgs a) { reg_chainback_alt_body<SP>(a); }
 template <class SP>
 __global__ void reg_export_kernel(RegExportArgs a) { reg_export_body<SP>(a); }
 
@@ -1524,7 +1524,7 @@ struct RegJitModule {
     hipFunction_t update[2] = {nullptr, nullptr};   // [0] 16-bit, [1] 8-bit metrics/symbols
     hipFunction_t resume[2] = {nullptr, nullptr};
     hipFunction_t chainback = nullptr, export_ = nullptr;
-    hipFunction_t chainback_coop = nullptr;         // K = 7, 9: the alternative body (reg_chainback_alt_body)
+    hipFunction_t chainback_alt = nullptr;         // K = 7, 9: the alternative body (reg_chainback_alt_body)
     unsigned chainback_frames_per_block = 32;
     kd::Table kernels;                              // kernel descriptors of the module's code object (kernel_desc.hpp)
 };
@@ -1606,8 +1606,8 @@ template <> int reg_launch_update<VIT_REG_ID>(int shift, const RegUpdateArgs& a,
 template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsigned tiles, hipStream_t st, bool coop) {
     using SP = RegSpecOf<VIT_REG_ID>::type;
     constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
-    if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
-    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_coop_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, true), st, a);
+    if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_alt_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
+    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_alt_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, true), st, a);
     else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, false), st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1650,7 +1650,7 @@ inline bool reg_kernel_resources(const RegCode& rc, int shift, int kind, kd::Ker
     if (rc.jit) {
         const char* name = kind == REG_KERNEL_UPDATE ? (shift ? "vit_jit_update_8" : "vit_jit_update_16")
                          : kind == REG_KERNEL_RESUME ? (shift ? "vit_jit_resume_8" : "vit_jit_resume_16")
-                         : kind == REG_KERNEL_CHAINBACK ? "vit_jit_chainback" : "vit_jit_chainback_coop";
+                         : kind == REG_KERNEL_CHAINBACK ? "vit_jit_chainback" : "vit_jit_chainback_alt";
         for (const auto& e : rc.jit->kernels)
             if (e.first == name) r = &e.second;
     } else {
@@ -1663,7 +1663,7 @@ inline bool reg_kernel_resources(const RegCode& rc, int shift, int kind, kd::Ker
         if (kind == REG_KERNEL_UPDATE) frag = {"17reg_update_kernelI", spec, tail};
         else if (kind == REG_KERNEL_RESUME) frag = {"17reg_resume_kernelI", spec, tail};
         else if (kind == REG_KERNEL_CHAINBACK) frag = {"20reg_chainback_kernelI", spec};
-        else frag = {"25reg_chainback_coop_kernelI", spec};
+        else frag = {"24reg_chainback_alt_kernelI", spec};
         r = kd::find(kd::own_library(), frag);
     }
     if (!r) return false;
@@ -1747,12 +1747,12 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     a.L = (u32)L;
     a.wave_priority = wave_priority;
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
-    // K = 7, 9: the other chainback kernel of the code (reg_chainback_alt_body) -- tests and experiments only
+    // K = 7, 9: the other chainback kernel of the code (reg_chainback_alt_body)
     bool coop = prefer_alt && (rc.K == 9 || rc.K == 7);
     if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';
     if (rc.jit) {
-        if (coop && rc.jit->chainback_coop)
-            return reg_jit_launch(rc.jit->chainback_coop, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st,
+        if (coop && rc.jit->chainback_alt)
+            return reg_jit_launch(rc.jit->chainback_alt, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st,
                                   reg_chainback_dyn_lds_bytes(rc.K, true));
         const unsigned fpb = rc.jit->chainback_frames_per_block;
         return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st,

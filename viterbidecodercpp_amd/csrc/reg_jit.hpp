@@ -187,7 +187,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
               << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_min_waves<SP>()) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
-            if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_coop(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";
+            if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_alt(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";
         }
         const std::string tmp = hsaco + "." + std::to_string((long)getpid()) + ".tmp";
         const int rc = run_child({hipcc, "-O3", "-std=c++17", "--offload-arch=" + arch, "--genco", "-o", tmp, src}, base + ".log", nullptr);
@@ -213,7 +213,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
     }
     m->chainback_frames_per_block = (K == 7 || K == 9) ? 128u : lane_bits == 0 ? 64u : 32u;
     (void)kd::parse_file(hsaco, m->kernels);           // an unreadable table only makes the pipeline pick its conservative schedule
-    if ((K == 9 || K == 7) && hipModuleGetFunction(&m->chainback_coop, m->module, "vit_jit_chainback_coop") != hipSuccess) m->chainback_coop = nullptr;
+    if ((K == 9 || K == 7) && hipModuleGetFunction(&m->chainback_alt, m->module, "vit_jit_chainback_alt") != hipSuccess) m->chainback_alt = nullptr;
     modules()[mkey] = m;
     return m;
 }

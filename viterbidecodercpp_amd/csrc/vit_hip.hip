@@ -861,6 +861,7 @@ int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedul
     s->workspace_bytes_each = p->ws_bytes;
     s->sub_batch_frames = p->sub_frames;
     s->chainback_wave_priority = (int32_t)p->cb_wave_priority;
+    s->chainback_small_kernel = (p->cb_small && s->chainback_overlapped) ? 1 : 0;
     return VIT_HIP_OK;
 }
 
