@@ -167,15 +167,15 @@ def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
     u = usage[k15[0]]
     cb = [k for k in usage if "lds2_chainback_kernel" in k]
     assert len(cb) == 1
-    for k in usage:                                             # every other large-K instantiation stays out of scratch
-        if "lds2_update_kernel" in k and k != k15[0] and "ILi15ELi8ELi6" not in k:
+    for k in usage:                                             # EVERY large-K instantiation stays out of scratch
+        if "lds2_update_kernel" in k:
             assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         if "lds2_update_kernel_c120" in k:
             # 512 threads per workgroup, two workgroups per CU = 4 waves per SIMD of 120 registers, and the chainback kernel's
             # allocation (granules of 8) beside them: 512 per SIMD
             assert 4 * usage[k]["alloc"] + usage[cb[0]]["alloc"] <= 512 and usage[k]["alloc"] <= 120, (k, usage[k], usage[cb[0]])
-    # (the 8-bit Cassini instantiation pays the cap with 16 bytes of scratch; the 16-bit one -- BASELINE configs[4] -- with none
-    # since the table build forms its lane number afresh)
+    # (round 3: the 8-bit Cassini instantiation paid the cap with 16 bytes of scratch; since the table build keeps ONE sum per lane
+    # and the symbols are paired on the scalar unit, none does)
     # two radix-16 groups per thread sit right at that budget, and since the block loop's control flow is scalar (step range
     # pinned uniform, the careful flag carried as a dword through v_readfirstlane) nothing is left in scratch; the fast
     # block (the code between two workgroup barriers that holds the 64 table reads and the eight 16-byte metric stores; ONE
@@ -200,8 +200,11 @@ def test_k15_kernel_fits_two_workgroups_per_cu(tmp_path):
         # unpacking of the table offsets, 70 the table build that four of the eight wavefronts run).  Round 2 stood at 834
         # vector instructions; the table-set toggle through one base register, loop-carried LDS offsets, scalar row bases for
         # the decision stores and unconditional symbol loads took out 40
+        # round 4: 753 -- the table build makes ONE sum per lane and stores it into both tables (table B is a permutation of
+        # table A), selects by mask instead of v_cmp + v_cndmask, and leaves the pairing of the two frames' symbols to the scalar
+        # unit of the four building wavefronts (K15 4096 x 8192: 49.3 -> 48.2 ms)
         valu = sum(1 for x in seg if x.strip().startswith("v_"))
-        assert valu <= 800, valu
+        assert valu <= 760, valu
         assert sum("flat_store" in x or "flat_load" in x for x in seg) == 0
     # the block loop branches on scalar conditions: its header compares the step counter in SGPRs
     hdr = body[body.index("This Loop Header: Depth=1"):]

@@ -278,7 +278,8 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
         for (int c = 0; c < BLK; ++c) xorB[c] = (u32)a.pattern[(size_t)1 << (GM::JB - 1 + c)] & 63u;
     }
-#ifndef VIT_L2_SCALAR_BUILD
+    // (An all-scalar build -- the symbols are wave-uniform -- was measured SLOWER in round 2: 14 VALU per table pair instead of 70, but
+    // 250 dependent scalar instructions in front of the building wavefronts' add-compare-select; they reached the block's barrier late.)
     // lane p: E[p] = sum_i |bt_i - y_i| with bt_i = high where bit i of p is set  (scalar.h:66-73); EB = max_error - E (:107),
     // stored at position lds2_tab_index(p): 70 VALU per table pair, on four of the eight wavefronts
     // `high` and `low` live in VECTOR registers for the build: the symbols are in SGPRs and a packed subtract takes only one
@@ -289,78 +290,29 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         l2_opaque(HIGH2v);
         l2_opaque(LOW2v);
     }
-    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
-        u32 e = 0, eb = 0;
+    // Table B (read by the threads' second groups) holds E[p ^ xb] where table A holds E[p] -- a PERMUTATION of the same 64 values:
+    // lane p computes E[p] once and stores it twice, at its place in table A and at the place of entry p ^ xb in table B (round 3
+    // summed both tables' entries per lane: 6 selects and 6 adds more per table pair)
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB) __attribute__((always_inline)) {
+        u32 e = 0;
         // the lane number is formed again here (two instructions, pinned): kept across the block it is one of the two values the
         // 120-register cap sends to scratch, reloaded behind a full vmcnt(0) right in front of the build
         u32 ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         l2_opaque(ln);
-        const u32 pb = ln ^ xb;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
-#ifdef VIT_L2_BUILD_CNDMASK
-                e = l2_add(e, ((ln >> i) & 1) ? a1 : a0);
-                eb = l2_add(eb, ((pb >> i) & 1u) ? a1 : a0);
-#else
-                // select by an all-ones / all-zeros mask of the lane's pattern bit (v_bfe_i32 + v_bitop3, 7 clocks) instead of
-                // v_cmp + v_cndmask through VCC (28: profiles/r4_op_rates.txt, v_cndmask_b32 alone issues once per 23 clocks)
-                const u32 mk = (u32)__builtin_amdgcn_sbfe((int)ln, (u32)i, 1u), mkb = (u32)__builtin_amdgcn_sbfe((int)pb, (u32)i, 1u);
+                // select by an all-ones / all-zeros mask of the lane's pattern bit (v_bfe_i32 + v_bitop3) instead of v_cmp + v_cndmask
+                const u32 mk = (u32)__builtin_amdgcn_sbfe((int)ln, (u32)i, 1u);
                 e = l2_add(e, __builtin_amdgcn_bitop3_b32(a1, a0, mk, 0xE4));
-                eb = l2_add(eb, __builtin_amdgcn_bitop3_b32(a1, a0, mkb, 0xE4));
-#endif
             }
         }
-        tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
-        if constexpr (GPT == 2) tab[64 + pos] = make_uint2(eb, l2_sub(MAXE2, eb));
+        const uint2 v = make_uint2(e, l2_sub(MAXE2, e));
+        tab[pos] = v;
+        if constexpr (GPT == 2) tab[64 + posB] = v;
     };
-#else
-    // EXPERIMENT, measured SLOWER (K15 4096 x 8192: 50.8 ms against 49.5): everything that does not depend on the lane on the
-    // scalar unit, one exec-masked packed add per symbol -- 14 VALU per table pair instead of 70, but 250 dependent scalar
-    // instructions in front of the building wavefronts' add-compare-select: they reach the block's barrier late and the other
-    // four wait for them.
-    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 xb, u32 pos) __attribute__((always_inline)) {
-        // The symbols are wave-uniform, so everything that does not depend on p runs on
-        // the SCALAR unit (idle in this VALU-bound kernel): per symbol a0 = |low - y|, a1 = |high - y| for both frames, the
-        // base sum S0 = sum a0 and the deltas d_i = a1 - a0.  E[p] = S0 + sum over the set bits of p of d_i is then ONE packed add
-        // per symbol under an exec mask that holds the lanes with bit i set (v_pk_add_u16 with the delta straight from an
-        // SGPR): 14 VALU per table pair, where per-lane selects took 70.
-        const int hi16 = (int)a.cfg.high, lo16 = (int)a.cfg.low;
-        auto absd = [](int expected, u32 sym16) __attribute__((always_inline)) -> u32 {
-            const int d = (int)(int16_t)(uint16_t)((u32)expected - sym16);          // soft_t(expected - sym), wrapping
-            return (u32)(d < 0 ? -d : d) & 0xFFFFu;                                 // error_t(get_abs(...)): |-32768| stays 0x8000
-        };
-        u32 sAl = 0, sAh = 0, sBl = 0, sBh = 0, dA[6], dB[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            dA[i] = 0; dB[i] = 0;
-            if (i < R) {
-                const u32 yl = y[i] & 0xFFFFu, yh = y[i] >> 16;
-                const u32 a1l = absd(hi16, yl), a0l = absd(lo16, yl), a1h = absd(hi16, yh), a0h = absd(lo16, yh);
-                const bool flip = (xb >> i) & 1u;            // table B holds E[p ^ xb]: where xb has bit i, a0 and a1 change places
-                sAl += a0l; sAh += a0h;
-                sBl += flip ? a1l : a0l; sBh += flip ? a1h : a0h;
-                const u32 dl = (a1l - a0l) & 0xFFFFu, dh = (a1h - a0h) & 0xFFFFu;
-                dA[i] = dl | (dh << 16);
-                dB[i] = flip ? (((0u - dl) & 0xFFFFu) | ((0u - dh) << 16)) : dA[i];
-            }
-        }
-        u32 e = (sAl & 0xFFFFu) | (sAh << 16), eb = (sBl & 0xFFFFu) | (sBh << 16);
-        constexpr uint64_t LANES[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
-                                       0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (i < R) {
-                e = l2_add_where(e, dA[i], LANES[i]);
-                if constexpr (GPT == 2) eb = l2_add_where(eb, dB[i], LANES[i]);
-            }
-        }
-        tab[pos] = make_uint2(e, l2_sub(MAXE2, e));
-        if constexpr (GPT == 2) tab[64 + pos] = make_uint2(eb, l2_sub(MAXE2, eb));   // the group-B table holds E[p ^ xb] where A holds E[p]
-    };
-#endif
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
     constexpr int CPW = GM::CPW;
     // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
@@ -373,36 +325,66 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { yland[i][k] = 0; ysym[i][k] = 0; }
     u32 tabpos[CPW];                         // where this lane's entry goes in the tables this wavefront builds (lds2_tab_index)
+    u32 tabxorB[CPW];                        // ... and, XORed onto it, where it goes in table B: the map is linear, index(p ^ xb) = index(p) ^ index(xb); wave-uniform
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         const int c = (wave + NW * i) & (BLK - 1);
         tabpos[i] = lds2_tab_index((u32)lane, a.idx_f[c], a.idx_t[c]);
+        tabxorB[i] = (u32)__builtin_amdgcn_readfirstlane((int)lds2_tab_index(xorB[c], a.idx_f[c], a.idx_t[c]));
     }
+    // Wavefronts beyond the block's four steps (K = 15, 16: eight / sixteen wavefronts) build no table.  Their symbol LOADS stay
+    // (a load under a condition turns the landing registers into phis of old and new values, live across the block: the 120-
+    // register cap then spills), but with a compile-time even rate and 16-bit symbols (RAW: the Cassini instantiation) everything
+    // behind the loads -- broadcasting the six raw dwords to SGPRs and pairing frame A's and frame B's symbols there, on the SCALAR
+    // unit (s_pack_ll / s_pack_hh) -- happens on the building wavefronts only; round 3 packed in vector registers (14 instructions)
+    // and broadcast (6) on all eight.
+    constexpr bool RAW = RT != 0 && SHIFT == 0 && RT % 2 == 0;
+    const bool builder = wave < BLK;                 // wave-uniform (wave comes from v_readfirstlane)
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
-            // unconditional, from a step clamped into the chunk [t_begin, t_end): a load under a condition makes the landing
-            // registers a phi of old and new values (six register copies on every path around it); what a clamped step
-            // fetches is never used (tables_build skips the steps outside the range)
+            // unconditional, from a step clamped into the chunk [t_begin, t_end): what a clamped step fetches is never used
+            // (tables_build skips the steps outside the range)
             u32 ts = t0 + (u32)((wave + NW * i) & (BLK - 1));
             ts = ts < t_begin ? t_begin : ts;
             ts = ts >= t_end ? t_end - 1u : ts;
-            load_syms(ts, yland[i]);
+            if constexpr (RAW) {
+                const size_t off = (size_t)(ts - t_begin) * (size_t)(RT * 2);
+#pragma unroll
+                for (int d = 0; d < RT / 2; ++d) {
+                    __builtin_memcpy(&yland[i][d], symA + off + 4 * d, 4);          // two 16-bit symbols of frame A (2-byte aligned)
+                    __builtin_memcpy(&yland[i][3 + d], symB + off + 4 * d, 4);      // ... and of frame B
+                }
+            } else {
+                load_syms(ts, yland[i]);
+            }
         }
     };
     auto tables_commit = [&]() __attribute__((always_inline)) {
+        if constexpr (RAW) {
+            if (NW > BLK && !builder) return;        // only SGPRs are written here
 #pragma unroll
-        for (int i = 0; i < CPW; ++i)
+            for (int i = 0; i < CPW; ++i)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ysym[i][k] = (u32)__builtin_amdgcn_readfirstlane((int)yland[i][k]);
+                for (int d = 0; d < RT / 2; ++d) {
+                    const u32 ra = (u32)__builtin_amdgcn_readfirstlane((int)yland[i][d]);
+                    const u32 rb = (u32)__builtin_amdgcn_readfirstlane((int)yland[i][3 + d]);
+                    ysym[i][2 * d] = (ra & 0xFFFFu) | (rb << 16);                    // (frame A | frame B << 16), symbol 2d
+                    ysym[i][2 * d + 1] = (ra >> 16) | (rb & 0xFFFF0000u);            // symbol 2d + 1
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ysym[i][k] = (u32)__builtin_amdgcn_readfirstlane((int)yland[i][k]);
+        }
     };
     auto tables_build = [&](u32 t0, int set) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
             if (c < BLK && t0 + (u32)c < t_end && t0 + (u32)c >= t_begin)
-                build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], c == 0 ? xorB[0] : c == 1 ? xorB[1] : c == 2 ? xorB[2] : xorB[3],
-                            tabpos[i]);
+                build_table(etab + (size_t)(set * BLK + c) * GPT * 64, ysym[i], tabpos[i], tabpos[i] ^ tabxorB[i]);
         }
     };
     // thread 0: could state 0 reach the threshold after one of the first three steps of the block at t_next, whose tables
