@@ -184,8 +184,10 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  *     higher wave priority than the updates (between two staggered update kernels the chainback would otherwise get the issue
  *     slots both leave over and become the bottleneck; here the fast register-ring kernel serves K = 7 too);
  *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9, R = 4: 368
- *     registers per wave; K = 7, R = 3: 2 x 248 + 32 > 512): a batch of up to two waves per SIMD is fed to the kernels as
- *     SUB-BATCHES of one wave per SIMD through the same three-workspace, two-update-stream schedule;
+ *     registers per wave; K = 7, R = 3: 2 x 248 + 32 > 512): ANY batch of more than one wave per SIMD is fed to the kernels as
+ *     SUB-BATCHES of one wave per SIMD through the same three-workspace, two-update-stream schedule (timing records and
+ *     vit_hip_pipeline_last_workspace are per sub-batch; an error in the middle of a submit() leaves the sub-batches already
+ *     enqueued in flight: sync() or destroy the pipeline before touching the buffers);
  *   - PLAN_LDS2 where the update waves a CU's LDS admits leave the chainback kernel's 24 registers on every SIMD (K = 11, 12,
  *     14, 15: four waves of at most 120; K = 13: three of 144): two workspaces, chainback beside the next update (K = 15,
  *     4096 frames: 51.6 -> 50.2 ms per batch; K = 13, 8192 x 4096: 16.4 -> 16.0);

@@ -122,6 +122,11 @@ public:
     void sync() {
         if (vit_hip_pipeline_sync(m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_sync");
     }
+    // the pipeline runs on private non-blocking streams: order the NEXT submitted batch behind a hipEvent_t the producer of its
+    // symbols recorded on its own stream (vit_hip_pipeline_wait_event); the other direction is submit()'s done_event
+    void wait_event(void* producer_event) {
+        if (vit_hip_pipeline_wait_event(m_pipe, producer_event) != VIT_HIP_OK) die("vit_hip_pipeline_wait_event");
+    }
     // which schedule the library chose for max_frames: workspaces, update kernels in flight, chainback overlap
     vit_hip_pipeline_schedule schedule() const {
         vit_hip_pipeline_schedule s;

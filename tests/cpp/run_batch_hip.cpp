@@ -74,6 +74,29 @@ int main() {
         HIP_OK(hipMemcpy(a.data(), d_out, a.size(), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(b.data(), d_out2, b.size(), hipMemcpyDeviceToHost));
         if (memcmp(a.data(), b.data(), a.size()) != 0) { printf("pipeline bytes differ from the serial decode\nFAIL\n"); return 1; }
+        // producer stream -> pipeline -> consumer stream with no host synchronisation in between: the symbols are still being
+        // copied into a fresh buffer when submit() is called (wait_event orders the update behind the copy), and the consumer's
+        // copy of the bytes waits on done_event
+        int16_t* d_sym2; uint8_t* d_out3;
+        hipStream_t producer, consumer; hipEvent_t ready, done;
+        HIP_OK(hipMalloc((void**)&d_sym2, frames * S * R * sizeof(int16_t)));
+        HIP_OK(hipMalloc((void**)&d_out3, frames * out_bytes));
+        HIP_OK(hipStreamCreateWithFlags(&producer, hipStreamNonBlocking)); HIP_OK(hipStreamCreateWithFlags(&consumer, hipStreamNonBlocking));
+        HIP_OK(hipEventCreate(&ready)); HIP_OK(hipEventCreate(&done));
+        HIP_OK(hipMemsetAsync(d_sym2, 0x55, frames * S * R * sizeof(int16_t), producer));
+        HIP_OK(hipMemsetAsync(d_out2, 0xA5, frames * out_bytes, producer));
+        HIP_OK(hipMemcpyAsync(d_sym2, d_sym, frames * S * R * sizeof(int16_t), hipMemcpyDeviceToDevice, producer));
+        HIP_OK(hipEventRecord(ready, producer));
+        pipe.wait_event(ready);
+        pipe.submit(d_sym2, frames, d_out2, nullptr, done);
+        HIP_OK(hipStreamWaitEvent(consumer, done, 0));
+        HIP_OK(hipMemcpyAsync(d_out3, d_out2, frames * out_bytes, hipMemcpyDeviceToDevice, consumer));
+        HIP_OK(hipStreamSynchronize(consumer));
+        HIP_OK(hipMemcpy(b.data(), d_out3, b.size(), hipMemcpyDeviceToHost));
+        if (memcmp(a.data(), b.data(), a.size()) != 0) { printf("pipeline ordered by events: bytes differ from the serial decode\nFAIL\n"); return 1; }
+        pipe.sync();
+        hipEventDestroy(ready); hipEventDestroy(done); hipStreamDestroy(producer); hipStreamDestroy(consumer);
+        hipFree(d_sym2); hipFree(d_out3);
         hipFree(d_out2);
     }
 
