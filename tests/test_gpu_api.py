@@ -155,6 +155,12 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     assert BatchDecoder(table, config).plan == _lib.PLAN_LDS          # AUTO does not compile anything behind the caller's back
     dec = check_batch_against_oracle(oracle, code, decode_type, 70, 384, 3.0, seed=K * R, plan=_lib.PLAN_REG)
     assert dec.plan == _lib.PLAN_REG
+    # the run-time compiled code object's kernel descriptors are readable too (the pipeline's residency rules need them): from
+    # the .hsaco in the cache directory
+    upd, cb = dec.kernel_resources(_lib.KERNEL_UPDATE), dec.kernel_resources(_lib.KERNEL_CHAINBACK)
+    assert 8 <= upd["vgpr_alloc"] <= 512 and upd["vgpr_alloc"] % 8 == 0 and 8 <= cb["vgpr_alloc"] <= 512, (upd, cb)
+    if K == 9:
+        assert cb["vgpr_alloc"] <= 32 and cb["lds_static_bytes"] == 0 and cb["lds_dynamic_bytes"] == 8 * 4096 + 8192, cb
     rng = np.random.default_rng(K)
     ss = rng.integers(0, code.num_states, 33).astype(np.int32)
     es = rng.integers(0, code.num_states, 33).astype(np.int32)

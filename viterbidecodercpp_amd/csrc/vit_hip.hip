@@ -661,17 +661,16 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
     vit_hip_pipeline* p = new (std::nothrow) vit_hip_pipeline();
     if (!p) return fail(VIT_HIP_ERR_RUNTIME, "out of host memory");
     p->h = h; p->max_frames = max_frames; p->L = L;
-    // Rule 1 -- chainback beside the next update.  The overlap pays while the update leaves register file and issue slots
-    // free: PLAN_REG with at most two update waves per SIMD (a 140-register wave; the chainback's 166 make a third resident).
-    // A larger batch fills the SIMDs by itself (measured: K7 131072 frames 8.70 ms overlapped vs 8.10 ms back to back), and the
-    // PLAN_LDS update takes whole CUs: those batches run back to back on one stream.  PLAN_LDS2 at K = 11, 12, 14, 15: the
-    // update kernel is capped at 120 registers, so the 24-register chainback finds room on every SIMD beside four update
-    // waves and runs beside the next batch's update (K15 4096 x 8192: 51.6 -> 50.3 ms per batch; with the 128-register update
-    // the same overlap gained 0.3 ms).
+    // Rule 1 -- chainback beside the next update.  The overlap pays while the update waves leave a chainback wave its registers
+    // (by the kernels' DESCRIPTORS, kernel_desc.hpp: 512 per SIMD) and LDS: PLAN_REG with at most two update waves per SIMD (three
+    // at K = 7 with the 32-register LDS-ring chainback).  A larger batch fills the SIMDs by itself (K7 131072 frames: 8.70 ms
+    // overlapped vs 8.10 ms back to back), and the PLAN_LDS update takes whole CUs: those batches run back to back on one stream.
+    // PLAN_LDS2: wherever the update waves a CU's LDS admits leave the chainback's 24 registers on every SIMD (K = 11, 12, 14, 15:
+    // four waves of at most 120 -- K15 4096 x 8192: 51.6 -> 50.3 ms per batch; K = 13: three of 144).
     // Rule 2 -- two updates in flight.  A batch of at most ONE update wave per SIMD (frames <= 4 x CUs x tile: the 32768-frame
     // share of BASELINE configs[3]) issues at the one-wave rate (5.27 cycles per packed instruction against 4.52 with two
     // waves, profiles/r2_dep_rate.txt): a second update stream and a third workspace put the next batch's update beside it
-    // (hard8 32768 x 8192: 2.01 -> 1.87 ms per batch, scripts/exp_pipeline3.py).
+    // (hard8 32768 x 8192: 2.01 -> 1.87 ms per batch; HISTORY.md, round 3).
     {
         int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -687,9 +686,10 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
         if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
     }
-    // Rule 3 -- sub-batches.  Where two update waves leave no registers for a chainback wave (K = 9: 2 x 256 of the SIMD's 512),
-    // the chainback of a two-waves-per-SIMD batch cannot run beside the next update at all: such a batch is fed to the kernels
-    // as sub-batches of one update wave per SIMD from the two update streams (K9 65536 x 8192: 14.2 -> 12.0 ms).
+    // Rule 3 -- sub-batches.  Where two update waves leave no registers (or LDS) for a chainback wave (K = 9, R = 4: one update
+    // wave allocates 368; K = 7, R = 3: 2 x 248 + 32; K = 7, R = 4: 8 x 16 KiB of LDS), the chainback of a two-waves-per-SIMD
+    // batch cannot run beside the next update at all: any batch of more than one wave per SIMD is fed to the kernels as sub-batches
+    // of one update wave per SIMD from the two update streams (LTE 65536 x 8192: 118 - 120 -> 133 - 145 Gbit/s).
     p->sub_frames = max_frames;
     p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
     if (h->plan == VIT_HIP_PLAN_REG && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames &&
