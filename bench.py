@@ -135,10 +135,13 @@ def pin_to_gpu_numa_node(index):
         gpus = []
         for n in sorted(int(x) for x in os.listdir(top)):
             props = {}
-            for line in open(f"{top}/{n}/properties"):
-                kv = line.split()
-                if len(kv) == 2:
-                    props[kv[0]] = kv[1]
+            try:
+                for line in open(f"{top}/{n}/properties"):
+                    kv = line.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+            except OSError:
+                continue            # a GPU of the host that this container may not open: not one of ours (HIP does not list it either)
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append(props)
         vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
@@ -536,6 +539,8 @@ def main():
     clock_load = clock_under_load() if clock_under_load is not None else (None, None)
     per_rank_info = None
     if world > 1:
+        if affinity and affinity.get("error") and rank == 0:
+            print(f"bench.py: rank 0 could not pin itself to its GPU's CPUs: {affinity['error']}", file=sys.stderr)
         mine = torch.tensor([clock_load[0] or 0.0, float(affinity["numa_node"]) if affinity and affinity["numa_node"] is not None else -1.0,
                              float(affinity["cpus_used"] or 0) if affinity else 0.0, 1.0 if affinity and affinity["pinned"] else 0.0],
                             dtype=torch.float64, device=coll_dev)
