@@ -38,6 +38,21 @@ def test_gpus_flag_must_agree_with_the_launcher_environment():
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
 
 
+def test_rank_pinning_is_best_effort_and_never_raises():
+    """bench.py pins each rank of an N > 1 run to the CPUs local to its GPU before its first GPU call (KFD topology -> DRM render
+    node -> local_cpulist).  Without a GPU (this container), with unreadable nodes (the host's other GPUs inside a one-GPU box) or
+    with an index past the visible GPUs it must report what happened and leave the affinity alone."""
+    sys.path.insert(0, ROOT)
+    import bench
+    before = os.sched_getaffinity(0)
+    for idx in (0, 99):
+        info = bench.pin_to_gpu_numa_node(idx)
+        assert set(info) >= {"gpu", "numa_node", "cpus_local", "cpus_used", "pinned"} and info["gpu"] == idx
+        if not info["pinned"]:
+            assert os.sched_getaffinity(0) == before
+    os.sched_setaffinity(0, before)
+
+
 @pytest.mark.gpu
 def test_gpus_2_spawns_two_ranks_on_one_card():
     """`python bench.py --gpus 2` with no launcher: the parent spawns two fresh rank processes (here both on cuda:0, gloo for
@@ -48,6 +63,10 @@ def test_gpus_2_spawns_two_ranks_on_one_card():
     assert r["ranks"]["world_size"] == 2 and r["ranks"]["ranks_in_blob_allreduce"] == 2
     assert r["ranks"]["blob_checksum_identical_on_all_ranks"] is True
     assert len(r["per_rank_Mbit_s"]) == 2 and all(v > 0 for v in r["per_rank_Mbit_s"])
+    # every rank reports where it was pinned (both ranks share cuda:0 here: the same NUMA node) and its own clock under load
+    pr = r["ranks"]["per_rank"]
+    assert len(pr) == 2 and all(500 < x["clock_mhz_under_load"] < 3000 for x in pr)
+    assert all(x["pinned_to_gpu_local_cpus"] and x["cpus"] >= 1 for x in pr), pr
     assert "cpu_baseline" not in r            # rank 0 at N=1 only
     assert 0 <= r["ber"] < 1e-2
 
