@@ -100,3 +100,38 @@ def test_synth_numpy_and_torch_encoders_agree():
     # noisy symbols stay inside the soft-decision range
     _, noisy = synth.make_frames_torch(code, pc, 3, 256, 1.0, seed=4, device="cpu")
     assert int(noisy.max()) <= pc.soft_decision_high and int(noisy.min()) >= pc.soft_decision_low
+
+
+def test_kernel_descriptor_reader_on_a_run_time_compiled_code_object(tmp_path):
+    """csrc/kernel_desc.hpp must read what `hipcc --genco` writes (an offload BUNDLE of code objects, not a bare ELF: the first
+    version of the reader saw nothing in it and every run-time compiled code silently got the conservative schedule) and agree
+    with the assembler's view of the same source: register allocation with LDS-occupancy padding, static LDS, scratch."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    kd_dump = os.path.join(ROOT, "tests", "cpp", "kd_dump")
+    if not os.path.exists(kd_dump):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "kd_dump"], check=True, capture_output=True)
+    src = tmp_path / "k.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n'
+                   'extern "C" __global__ void __launch_bounds__(64) padded(int* p) { __shared__ int big[10240]; big[threadIdx.x] = p[threadIdx.x]; '
+                   '__syncthreads(); p[threadIdx.x] = big[63 - threadIdx.x]; }\n'                       # 40 KiB of STATIC LDS: one wave per SIMD
+                   'extern "C" __global__ void __launch_bounds__(64) lean(int* p) { extern __shared__ int dyn[]; dyn[threadIdx.x] = p[threadIdx.x]; '
+                   '__syncthreads(); p[threadIdx.x] = dyn[63 - threadIdx.x]; }\n')                      # the same with dynamic LDS
+    hsaco, asm = tmp_path / "k.hsaco", tmp_path / "k.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "--genco", "-o", str(hsaco), str(src)], check=True, capture_output=True)
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm), str(src)], check=True, capture_output=True)
+    assert open(hsaco, "rb").read(24) == b"__CLANG_OFFLOAD_BUNDLE__"
+    got = {}
+    for line in subprocess.run([kd_dump, str(hsaco)], check=True, capture_output=True, text=True).stdout.splitlines():
+        v, a, l, s, name = line.split()
+        got[name] = (int(v), int(l), int(s))
+    text = asm.read_text()
+    for name in ("padded", "lean"):
+        m = re.search(r"\.amdhsa_kernel " + name + r"\n(.*?)\.end_amdhsa_kernel", text, re.S).group(1)
+        f = lambda k: int(re.search(r"\.amdhsa_" + k + r" (\d+)", m).group(1))  # noqa: E731
+        assert got[name] == (-(-f("next_free_vgpr") // 8) * 8, f("group_segment_fixed_size"), f("private_segment_fixed_size")), (name, got[name])
+    # the finding itself, kept as a regression: static LDS that admits one wave per SIMD pads the allocation past 256 registers
+    assert got["padded"][0] >= 264 and got["padded"][1] == 40960 and got["lean"][0] <= 32 and got["lean"][1] == 0, got

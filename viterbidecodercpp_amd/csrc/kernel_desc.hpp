@@ -92,7 +92,33 @@ inline bool parse_code_object(const uint8_t* p, size_t n, Table& out) {
     return true;
 }
 
-// a file that is either a code object itself (.hsaco) or a host ELF whose .hip_fatbin section holds clang offload bundles
+// every AMDGPU code object inside the clang offload bundles that start on 4 KiB boundaries of [p, p + n): magic, u64 entry count,
+// then per entry {u64 offset, u64 size, u64 triple length, triple}
+inline bool parse_bundles(const uint8_t* p, size_t n, Table& out) {
+    using namespace detail;
+    static const char MAGIC[] = "__CLANG_OFFLOAD_BUNDLE__";
+    bool any = false;
+    for (uint64_t b = 0; b + 32 <= n; b += 4096) {
+        const uint8_t* h = p + b;
+        if (memcmp(h, MAGIC, 24) != 0) continue;
+        const uint64_t count = rd64(h + 24);
+        uint64_t q = 32;
+        for (uint64_t i = 0; i < count && b + q + 24 <= n; ++i) {
+            const uint64_t off = rd64(h + q), size = rd64(h + q + 8), tl = rd64(h + q + 16);
+            q += 24;
+            if (tl > n - b - q) break;
+            const std::string triple((const char*)h + q, (size_t)tl);
+            q += tl;
+            if (size == 0 || triple.find("amdgcn") == std::string::npos) continue;
+            if (off > n - b || size > n - b - off) continue;
+            any = parse_code_object(h + off, (size_t)size, out) || any;
+        }
+    }
+    return any;
+}
+
+// a file that is a code object itself, an offload bundle of code objects (what `hipcc --genco` writes: .hsaco), or a host ELF
+// whose .hip_fatbin section holds one bundle per translation unit
 inline bool parse_file(const std::string& path, Table& out) {
     using namespace detail;
     std::vector<uint8_t> buf;
@@ -109,7 +135,8 @@ inline bool parse_file(const std::string& path, Table& out) {
     }
     const uint8_t* p = buf.data();
     const size_t n = buf.size();
-    if (n >= 64 && rd16(p + 0x12) == 224) return parse_code_object(p, n, out);
+    if (n >= 24 && memcmp(p, "__CLANG_OFFLOAD_BUNDLE__", 24) == 0) return parse_bundles(p, n, out);
+    if (n >= 64 && memcmp(p, "\x7f" "ELF", 4) == 0 && rd16(p + 0x12) == 224) return parse_code_object(p, n, out);
     std::vector<Section> sec;
     uint16_t shstrndx = 0;
     if (!elf_sections(p, n, sec, &shstrndx)) return false;
@@ -117,24 +144,7 @@ inline bool parse_file(const std::string& path, Table& out) {
     bool any = false;
     for (const Section& s : sec) {
         if (s.name >= names.size || strncmp((const char*)p + names.off + s.name, ".hip_fatbin", (size_t)(names.size - s.name)) != 0) continue;
-        // bundles start on 4 KiB boundaries: magic, u64 entry count, then per entry {u64 offset, u64 size, u64 triple length, triple}
-        static const char MAGIC[] = "__CLANG_OFFLOAD_BUNDLE__";
-        for (uint64_t b = 0; b + 32 <= s.size; b += 4096) {
-            const uint8_t* h = p + s.off + b;
-            if (memcmp(h, MAGIC, 24) != 0) continue;
-            const uint64_t count = rd64(h + 24);
-            uint64_t q = 32;
-            for (uint64_t i = 0; i < count && b + q + 24 <= s.size; ++i) {
-                const uint64_t off = rd64(h + q), size = rd64(h + q + 8), tl = rd64(h + q + 16);
-                q += 24;
-                if (tl > s.size - b - q) break;
-                const std::string triple((const char*)h + q, (size_t)tl);
-                q += tl;
-                if (size == 0 || triple.find("amdgcn") == std::string::npos) continue;
-                if (off > s.size - b || size > s.size - b - off) continue;
-                any = parse_code_object(h + off, (size_t)size, out) || any;
-            }
-        }
+        any = parse_bundles(p + s.off, (size_t)s.size, out) || any;
     }
     return any;
 }
