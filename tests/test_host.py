@@ -63,6 +63,24 @@ def test_argument_errors_come_before_device_access():
     assert lib.vit_hip_create_from_blob(p(np.zeros(4, np.uint8)), 4, 0, C.byref(h)) == _lib.ERR_INVALID_ARG
 
 
+def test_kernel_table_is_readable_without_a_gpu_and_argument_errors_are_reported():
+    """vit_hip_list_kernels reads the library's own code objects from disk (no device needed): every stock update / chainback kernel
+    is in it with a sane allocation; the handle-bound query and the new pipeline entry point reject NULL arguments."""
+    lib = _lib.load()
+    table = _lib.list_kernels()
+    assert len(table) >= 90
+    for frag in ("17reg_update_kernelINS_7RegSpecILi7ELi2ELj109ELj79E", "20reg_chainback_kernelINS_7RegSpecILi9ELi2ELj491ELj369E",
+                 "24reg_chainback_alt_kernelINS_7RegSpecILi7ELi2E", "23lds2_update_kernel_c120ILi15ELi0ELi6E", "21lds2_chainback_kernelE"):
+        hits = [v for k, v in table.items() if frag in k]
+        assert hits and all(8 <= v["vgpr_alloc"] <= 512 and v["vgpr_alloc"] % 8 == 0 for v in hits), frag
+    r = _lib.VitHipKernelResources()
+    name = C.create_string_buffer(8)
+    assert lib.vit_hip_list_kernels(0, name, len(name), C.byref(r)) == _lib.OK and len(name.value) == 7     # truncated, terminated
+    assert lib.vit_hip_list_kernels(10 ** 6, name, len(name), C.byref(r)) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_get_kernel_resources(None, 0, C.byref(r)) == _lib.ERR_INVALID_ARG
+    assert lib.vit_hip_pipeline_wait_event(None, None) == _lib.ERR_INVALID_ARG
+
+
 def test_no_cpu_fallback_without_gpu():
     """on a machine without a GPU the product path must fail loudly, never decode on the CPU."""
     import torch
