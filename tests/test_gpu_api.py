@@ -308,6 +308,35 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     assert lib.vit_hip_pipeline_destroy(pipe) == _lib.OK
 
 
+@pytest.mark.parametrize("K,R,G,F", [(7, 2, (0o171, 0o133), 40000), (9, 2, (0o557, 0o663), 40000), (7, 2, (0o171, 0o133), 70000)])
+def test_decode_pipeline_with_a_run_time_compiled_code(K, R, G, F):
+    """the pipeline's residency rules and its small-footprint chainback kernel for a code that exists only as a run-time compiled
+    module: descriptors come from the .hsaco (an offload bundle), the K = 7 chainback beside the update is the module's LDS-ring
+    kernel with its dynamic LDS, and the schedule is the stock codes' (two / three update waves per SIMD + chainback: overlapped)."""
+    import torch
+    from viterbidecodercpp_amd import DecodePipeline
+
+    code = Code(f"custom K{K}", K, R, tuple(G))
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config, plan=_lib.PLAN_REG)
+    L = 64
+    pipe = DecodePipeline(dec, F, L)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus == 256:
+        assert (pipe.schedule.workspaces, pipe.schedule.update_streams, pipe.schedule.chainback_overlapped) == (2, 1, 1)
+        assert pipe.schedule.chainback_small_kernel == (1 if K == 7 else 0) and pipe.schedule.sub_batch_frames == F
+    outs = []
+    for k in range(4):
+        tx, sym = dec.synth(F, L, 3.0, seed=300 + k)
+        out = torch.zeros((F, L // 8), dtype=torch.uint8, device="cuda")
+        pipe.submit(sym, out)
+        outs.append((sym, out))
+    pipe.sync()
+    for sym, out in outs:
+        assert torch.equal(out, dec.decode(sym, L))
+    pipe.close()
+
+
 def test_decode_pipeline_orders_itself_against_torch_streams():
     """DecodePipeline runs on private non-blocking streams (round-3 advisor: a data race for `sym = synth(...); submit(sym)`).
     submit() now orders each batch behind torch's current stream (vit_hip_pipeline_wait_event) and wait_done() orders the current
