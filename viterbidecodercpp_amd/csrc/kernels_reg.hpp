@@ -221,6 +221,37 @@ struct RegSpec {
     }
 };
 
+// ---- branch metrics fetched in SUB-CHUNKS (K = 9 with sixteen patterns: CDMA 2000) --------------------------------------
+// A step's 2^R sums {E[p], max_error - E[p]} are 32 registers at R = 4, 64 with the one-step look-ahead double buffer -- on
+// top of 64 metrics and 32 live decision values that is 368 allocated registers and ONE wave per SIMD.  Here the butterflies of
+// a step are taken in sub-chunks of CS = 4 and each sub-chunk fetches the (at most four) patterns the NEXT one needs: 16
+// registers instead of 64, the price being 32 instead of 16 ds_read_b64 per step (the LDS has the room: a quarter of its
+// cycles).  All compile time: which butterfly of a sub-chunk is the first to use a pattern, and the register slot it lands in.
+template <class SP>
+struct RegChunk {
+    static constexpr int CS = 4;
+    static constexpr int NSUB = SP::NREG / 2 / CS;
+    // (total functions: the generic lambdas that call them are instantiated for every code, also where their results are unused)
+    static constexpr int pb(int PH) { return SP::lane_phase(PH % SP::SB) ? SP::T : SP::pbit(PH % SP::SB); }   // classic lane phases only (no X3)
+    static constexpr int r0(int PH, int h) {
+        const int PB = pb(PH);
+        return ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
+    }
+    static constexpr u32 pat(int PH, int h) { return SP::pat_reg(PH % SP::SB, (u32)r0(PH, h)); }
+    static constexpr int first(int PH, int h) {
+        for (int k = h / CS * CS; k < h; ++k)
+            if (pat(PH, k) == pat(PH, h)) return k;
+        return h;
+    }
+    static constexpr int slot(int PH, int h) {
+        const int f = first(PH, h);
+        int n = 0;
+        for (int k = h / CS * CS; k < f; ++k)
+            if (first(PH, k) == k) ++n;
+        return n;
+    }
+};
+
 struct RegUpdateArgs {
     const uint8_t* symbols;
     size_t sym_frame_stride_bytes;
@@ -299,7 +330,12 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int U0 = clcm(clcm(PER, GROUP), SPS);
     // LDS ring, in steps: the slot of step t is t % RING, a compile-time constant because RING divides the block length; 16 KiB
     // per wave at most, so that eight waves still fit a CU (R = 4 with 6 state bits: 8 steps, block of 24)
-    constexpr int RING = !LDSBM ? 1 : (U0 * NP * 128 <= 16384 ? U0 : 8);
+    // K = 9, R = 3, 4: branch metrics fetched per sub-chunk of four butterflies instead of per step (RegChunk).  Their LDS ring
+    // holds ONE group of four steps (8 KiB per wave at R = 4, so that eight update waves and two 40 KiB chainback workgroups share
+    // a CU): the next group is produced at the END of a group's last step, behind the last fetch of the old one
+    constexpr bool BMCHUNK = LDSBM && !SP::X3 && NREG >= 64 && NP >= 8;
+    using RC = RegChunk<SP>;
+    constexpr int RING = !LDSBM ? 1 : BMCHUNK ? GROUP : (U0 * NP * 128 <= 16384 ? U0 : 8);
     // the 16-register codes (K = 7) unroll two periods (24 steps) so that the symbol ring below can run six groups ahead
     constexpr int U = LDSBM ? clcm(clcm(U0, RING), NREG == 16 ? 24 : 1) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
     constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
@@ -479,7 +515,8 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // step `un` (un == U: step 0 of the NEXT block, whose chunks are already refilled).  Depends on symbols only, so it is
     // computed one step AHEAD, inside the basic block of the previous step's add-compare-select: its dependent chain
     // (perm -> sub -> neg -> max -> add -> sub) then overlaps ACS work instead of stalling the start of every step.
-    u32 E[2][NP], EB[2][NP];
+    u32 E[2][BMCHUNK ? 1 : NP], EB[2][BMCHUNK ? 1 : NP];
+    u32 Ec[2][RC::CS], EBc[2][RC::CS];           // BMCHUNK: [sub-chunk parity][slot]
     auto branch_metrics = [&](auto unc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value;
         constexpr int us = un % U;            // position inside the (current or next) block
@@ -560,11 +597,33 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             EB[buf][p] = v.y;
         });
     };
+    // BMCHUNK consumer: the patterns sub-chunk `s` of block step `un` needs (un == U: step 0 of the next block)
+    auto bm_fetch_chunk = [&](auto unc, auto sc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value, s = decltype(sc)::value;
+        constexpr int us = un % U, PHn = us % PER, buf = s & 1;
+        static_for<RC::CS>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int h = s * RC::CS + decltype(kc)::value;
+            if constexpr (RC::first(PHn, h) == h) {
+                constexpr u32 p = RC::pat(PHn, h);
+                constexpr int sl = RC::slot(PHn, h);
+                // byte offset of entry (p ^ x, g): formed HERE, one v_xor_b32 with a literal per read (2.7 clocks: all-VGPR/literal
+                // 32-bit class).  Left to hipcc the 8 x 16 loop-invariant addresses are hoisted out of the block loop and the
+                // kernel spills them (104 bytes of scratch at the 240-register cap); asm volatile keeps the xor where it is
+                static_assert(!BMCHUNK || !RDTAB, "sub-chunk fetches form their addresses from rd_x");
+                u32 off = rd_x[BMCHUNK ? PHn : 0] << 3;
+                if constexpr (p != 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "n"(p << 7), "v"(off));
+                const uint2 v = *(const uint2*)((const char*)bm_ring + off + (us % RING) * ROW * 8);
+                Ec[buf][sl] = v.x;
+                EBc[buf][sl] = v.y;
+            }
+        });
+    };
     if constexpr (LDSBM) {
         static_for<NG>([&](auto sc) __attribute__((always_inline)) { load_group(tb0 + (u32)(decltype(sc)::value * GROUP), sc); });
         bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         load_group(tb0 + (u32)(NG * GROUP), std::integral_constant<int, 0>{});
-        bm_fetch(std::integral_constant<int, 0>{});
+        if constexpr (BMCHUNK) bm_fetch_chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        else bm_fetch(std::integral_constant<int, 0>{});
     } else {
         branch_metrics(std::integral_constant<int, 0>{});
     }
@@ -587,14 +646,14 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             constexpr int cur = u & 1;
             if (!GUARDED || t0 + u < a.t_end) {
                 if constexpr (LDSBM) {
-                    if constexpr (u % GROUP == 0) {
+                    if constexpr (!BMCHUNK && u % GROUP == 0) {
                         // first step of block group Jb: produce group Jb + 1, then refill its symbol slot with group Jb + 1 + NG
                         constexpr int Jb = u / GROUP;
                         constexpr int sl = (Jb + 1) % NG;
                         bm_produce(std::integral_constant<int, (GROUP * (Jb + 1)) % RING>{}, std::integral_constant<int, sl>{});
                         load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
                     }
-                    bm_fetch(std::integral_constant<int, u + 1>{});
+                    if constexpr (!BMCHUNK) bm_fetch(std::integral_constant<int, u + 1>{});
                 } else {
                     branch_metrics(std::integral_constant<int, u + 1>{});
                 }
@@ -676,14 +735,30 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     constexpr int r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
                     constexpr int r1 = r0 | (1 << PB);
                     constexpr u32 p = SP::pat_reg(PH, (u32)r0);
+                    if constexpr (BMCHUNK && h % RC::CS == 0) {
+                        // first butterfly of a sub-chunk: ask for the next sub-chunk's patterns (the last one: for the first of step u + 1)
+                        // (the first of a NEW group comes from the produce at the end of this step)
+                        if constexpr (h / RC::CS + 1 < RC::NSUB) bm_fetch_chunk(uc, std::integral_constant<int, h / RC::CS + 1>{});
+                        else if constexpr (u % GROUP != GROUP - 1) bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    u32 e_p, eb_p;
+                    if constexpr (BMCHUNK) {
+                        static_assert(RC::r0(PH, h) == r0 && RC::pat(PH, h) == p, "RegChunk mirrors the butterfly enumeration");
+                        e_p = Ec[(h / RC::CS) & 1][RC::slot(PH, h)];
+                        eb_p = EBc[(h / RC::CS) & 1][RC::slot(PH, h)];
+                    } else {
+                        e_p = E[cur][p];
+                        eb_p = EB[cur][p];
+                    }
                     const u32 ma = m[r0], mb = m[r1];
 #ifdef VIT_EXPERIMENT_ADD32
                     // TIMING EXPERIMENT ONLY (results wrong whenever a low half carries): the ceiling of VOP2 adds
-                    const u32 x0 = ma + E[cur][p], y0 = mb + EB[cur][p];
-                    const u32 x1 = ma + EB[cur][p], y1 = mb + E[cur][p];
+                    const u32 x0 = ma + e_p, y0 = mb + eb_p;
+                    const u32 x1 = ma + eb_p, y1 = mb + e_p;
 #else
-                    const u32 x0 = pk_add(ma, E[cur][p]), y0 = pk_add(mb, EB[cur][p]);   // -> next state (X|0)
-                    const u32 x1 = pk_add(ma, EB[cur][p]), y1 = pk_add(mb, E[cur][p]);   // -> next state (X|1)
+                    const u32 x0 = pk_add(ma, e_p), y0 = pk_add(mb, eb_p);   // -> next state (X|0)
+                    const u32 x1 = pk_add(ma, eb_p), y1 = pk_add(mb, e_p);   // -> next state (X|1)
 #endif
                     m[r0] = pk_min_s(x0, y0);
                     m[r1] = pk_min_s(x1, y1);
@@ -816,6 +891,18 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         rsB += (uint64_t)((sub >> 16) >> SHIFT);
                     }
                 }
+                } else if constexpr (BMCHUNK && u % GROUP != GROUP - 1) {
+                    // a step below t_begin of a resumed call: only the look-ahead the skipped butterflies would have issued
+                    bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
+                }
+                if constexpr (BMCHUNK && u % GROUP == GROUP - 1) {
+                    // last step of block group Jb, every fetch of the group issued (LDS operations of a wave complete in order):
+                    // produce group Jb + 1 over it, refill its symbol slot with group Jb + 1 + NG, fetch the new group's first sub-chunk
+                    constexpr int Jb = u / GROUP;
+                    constexpr int sl = (Jb + 1) % NG;
+                    bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, sl>{});
+                    load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
+                    bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
                 }
             }
         });
@@ -1004,10 +1091,15 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
 #define VIT_REG_CB_RING_DEPTH_K7 4
 #endif
 // ---- lane-local chainback through an LDS ring (K = 7, K = 9): one lane per frame PAIR, 128 frames per wave ----
-// ring slots of four 1 KiB rows + 8 KiB of parked output dwords: 8 slots at K = 9 (40 KiB), 4 at K = 7 (24 KiB: three of these
-// workgroups and the twelve update waves of a three-waves-per-SIMD batch share a CU's 160 KiB)
-constexpr int reg_cb_ring_depth(int nreg) { return nreg == 16 ? VIT_REG_CB_RING_DEPTH_K7 : 8; }
-constexpr unsigned reg_cb_ring_lds_bytes(int nreg) { return (unsigned)reg_cb_ring_depth(nreg) * 4096u + 8192u; }
+// ring slots of four 1 KiB rows + parked output dwords (512 B per iteration between flushes): 8 slots + 16 iterations at K = 9
+// (40 KiB), 4 + 16 at K = 7 (24 KiB: three of these workgroups and the twelve update waves of a three-waves-per-SIMD batch share a
+// CU's 160 KiB), 2 + 8 at K = 7 with sixteen branch patterns (12 KiB: the R = 4 update waves hold 16 KiB of branch-metric ring
+// each, and eight of them plus two of these workgroups must fit a CU -- DAB Radio on the overlapped schedule)
+constexpr int reg_cb_ring_depth(int nreg, int R) { return nreg == 16 ? (R >= 4 ? 2 : VIT_REG_CB_RING_DEPTH_K7) : 8; }
+constexpr int reg_cb_ring_flush_iters(int nreg, int R) { return (nreg == 16 && R >= 4) ? 8 : 16; }
+constexpr unsigned reg_cb_ring_lds_bytes(int nreg, int R) {
+    return (unsigned)reg_cb_ring_depth(nreg, R) * 4096u + (unsigned)reg_cb_ring_flush_iters(nreg, R) * 512u;
+}
 // A step's decisions of a tile are 64 lanes x 16 B / SPS and the chase needs ONE bit per frame of them.  Here the rows never
 // touch a register: the wave streams the 1 KiB rows of FOUR tiles into an LDS ring with direct-to-LDS loads
 // (global_load_lds_dwordx4, each row in its own order; counted vmcnt waits), and each lane reads the one BYTE that holds its
@@ -1028,16 +1120,16 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
     // ring depth in rows (divides ROWS_IT).  K = 9, beside an update kernel: 4, 8 and 16 rows move the same bytes per second
     // (the chase waits for issue slots, not for rows) but 16 -- 72 KiB of LDS per wave -- keep update waves off the CU (12.6 ->
     // 14.1 ms per batch)
-    constexpr int D = reg_cb_ring_depth(SP::NREG);
+    constexpr int D = reg_cb_ring_depth(SP::NREG, SP::R);
     static_assert(ROWS_IT % D == 0, "ring slots are compile-time constants");
-    constexpr int KI = 16;                                     // iterations between flushes: 64 output bytes per frame
+    constexpr int KI = reg_cb_ring_flush_iters(SP::NREG, SP::R);   // iterations between flushes: 4 output bytes per frame each
     // the top step of every iteration: t = CT mod 32 (its last decoded bit j = t - SB is a multiple of 32)
     constexpr int CT = (ITER - 1 + SB) % ITER;
     // DYNAMIC LDS (reg_cb_ring_lds_bytes() at launch), on purpose: hipcc pads the register allocation of a kernel whose STATIC LDS
     // limits its occupancy up to the count that enforces that occupancy (40 KiB per one-wave workgroup = one wave per SIMD =
     // .amdhsa_next_free_vgpr 257 for the 22 registers this body uses), and a 264-register wave does not fit beside two update
     // waves.  With the size unknown at compile time the descriptor says what the body needs (tests/test_codegen.py reads it).
-    static_assert(reg_cb_ring_lds_bytes(SP::NREG) == D * 4 * 64 * 16 + 2 * KI * 64 * 4, "launch size of the ring kernels");
+    static_assert(reg_cb_ring_lds_bytes(SP::NREG, SP::R) == D * 4 * 64 * 16 + 2 * KI * 64 * 4, "launch size of the ring kernels");
     extern __shared__ uint4 reg_cb_dyn_lds[];
     uint4* const ring = reg_cb_dyn_lds;                        // [slot][tile of the wave][lane of the row]
     u32* const obuf = (u32*)(reg_cb_dyn_lds + D * 4 * 64);     // [frame half][iteration][lane]
@@ -1434,18 +1526,22 @@ VIT_DEV void reg_export_body(const RegExportArgs& a) {
 }
 
 // ---- kernels: thin __global__ wrappers (the bodies above are shared with the run-time compiled instantiations) --------
-// two waves per SIMD (<= 256 VGPRs) wherever the tiles of a 65536-frame batch outnumber the SIMDs two to one: left alone
-// hipcc takes 260 registers for K = 9 and halves the occupancy.  K = 9 with R > 2 does not fit (64 metrics + 64 decisions + 64
-// branch metrics) and keeps one wave per SIMD.
+// two waves per SIMD (<= 256 VGPRs) for every code: the tiles of a 65536-frame batch outnumber the SIMDs two to one, and a lone
+// wave issues at 5.4 - 5.9 clocks per instruction where two reach 4.5.
 template <class SP>
-constexpr int reg_update_min_waves() { return (SP::NREG >= 64 && SP::R > 2) ? 1 : 2; }
-// K = 9, R = 2: capped at 240 registers (the attribute counts in halves of the unified file: 120).  hipcc's schedule for 256
-// holds no more live values than fit 240 (no scratch either way), the capped kernel runs 2.7 % FASTER (10.99 vs 11.29 ms,
-// 65536 x 8192) and two of its waves leave 32 registers per SIMD: the K = 9 chainback's allocation (reg_chainback_ring_body)
+constexpr int reg_update_min_waves() { return 2; }
+// Capped at 240 registers (the attribute counts in halves of the unified file: 120) where hipcc would take more: two such waves
+// leave 32 registers per SIMD -- the allocation of the LDS-ring chainback kernel (24 at K = 9, 32 at K = 7), which then runs
+// BESIDE the next batch's update (vit_hip_pipeline_create, rule 1).
+//   K = 9, R = 2 (IS-95A): hipcc's schedule for 256 holds no more live values than fit 240 (no scratch either way), the capped
+//          kernel runs 2.7 % FASTER (10.99 vs 11.29 ms, 65536 x 8192);
+//   K = 9, R = 4 (CDMA 2000): 217 used with the sub-chunk branch-metric fetch (RegChunk; 368 allocated -- ONE wave per SIMD --
+//          with the whole-step double buffer);
+//   K = 7, R = 3 (LTE): 248 -> 240, no scratch.
 // (the attribute takes a literal, not a template-dependent value: the translation unit of the code sets it -- reg_inst.hip
-// with -DVIT_REG_ID=3, reg_jit.hpp for a run-time compiled K = 9, R = 2 code)
+// with -DVIT_REG_ID=1, 3, 4, reg_jit.hpp for the run-time compiled codes of those geometries)
 #if !defined(VIT_REG_UPDATE_VGPR_CAP) && defined(VIT_REG_ID)
-#if VIT_REG_ID == 3
+#if VIT_REG_ID == 1 || VIT_REG_ID == 3 || VIT_REG_ID == 4
 #define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))
 #endif
 #endif
@@ -1468,8 +1564,8 @@ VIT_DEV void reg_chainback_body(const RegChainbackArgs& a) {
     else reg_chainback_coop_body<SP>(a);
 }
 // dynamic LDS of a code's chainback kernel (`alt`: of its alternative kernel): the LDS-ring body is K = 9's kernel and K = 7's alternative
-constexpr unsigned reg_chainback_dyn_lds_bytes(int K, bool alt) {
-    return (K == 9 && !alt) ? reg_cb_ring_lds_bytes(64) : (K == 7 && alt) ? reg_cb_ring_lds_bytes(16) : 0u;
+constexpr unsigned reg_chainback_dyn_lds_bytes(int K, int R, bool alt) {
+    return (K == 9 && !alt) ? reg_cb_ring_lds_bytes(64, R) : (K == 7 && alt) ? reg_cb_ring_lds_bytes(16, R) : 0u;
 }
 template <class SP>
 constexpr unsigned reg_chainback_frames_per_block() { return (SP::NREG == 16 || SP::NREG == 64) && SP::LANE_BITS == 2 ? 128u : SP::LANE_BITS == 0 ? 64u : 32u; }
@@ -1607,8 +1703,8 @@ template <> int reg_launch_chainback<VIT_REG_ID>(const RegChainbackArgs& a, unsi
     using SP = RegSpecOf<VIT_REG_ID>::type;
     constexpr unsigned FPB = reg_chainback_frames_per_block<SP>();
     if (coop && SP::NREG == 64) hipLaunchKernelGGL(reg_chainback_alt_kernel<SP>, dim3(tiles), dim3(64), 0, st, a);
-    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_alt_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, true), st, a);
-    else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, false), st, a);
+    else if (coop && SP::NREG == 16 && SP::LANE_BITS == 2) hipLaunchKernelGGL(reg_chainback_alt_kernel<SP>, dim3((a.frames + 127) / 128), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, SP::R, true), st, a);
+    else hipLaunchKernelGGL(reg_chainback_kernel<SP>, dim3((a.frames + FPB - 1) / FPB), dim3(64), reg_chainback_dyn_lds_bytes(SP::K, SP::R, false), st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <> int reg_launch_export<VIT_REG_ID>(const RegExportArgs& a, unsigned blocks, hipStream_t st) {
@@ -1644,8 +1740,8 @@ template <> int reg_launch_export<6>(const RegExportArgs&, unsigned, hipStream_t
 // occupancy -- round 3's K = 9 chainback used 22 registers and allocated 264)
 enum RegKernelKind { REG_KERNEL_UPDATE = 0, REG_KERNEL_CHAINBACK = 1, REG_KERNEL_CHAINBACK_ALT = 2, REG_KERNEL_RESUME = 3 };
 inline bool reg_kernel_resources(const RegCode& rc, int shift, int kind, kd::KernelResources* out, unsigned* dyn_lds_bytes = nullptr) {
-    if (dyn_lds_bytes) *dyn_lds_bytes = kind == REG_KERNEL_CHAINBACK ? reg_chainback_dyn_lds_bytes(rc.K, false)
-                                      : kind == REG_KERNEL_CHAINBACK_ALT ? reg_chainback_dyn_lds_bytes(rc.K, true) : 0u;
+    if (dyn_lds_bytes) *dyn_lds_bytes = kind == REG_KERNEL_CHAINBACK ? reg_chainback_dyn_lds_bytes(rc.K, rc.R, false)
+                                      : kind == REG_KERNEL_CHAINBACK_ALT ? reg_chainback_dyn_lds_bytes(rc.K, rc.R, true) : 0u;
     const kd::KernelResources* r = nullptr;
     if (rc.jit) {
         const char* name = kind == REG_KERNEL_UPDATE ? (shift ? "vit_jit_update_8" : "vit_jit_update_16")
@@ -1753,10 +1849,10 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     if (rc.jit) {
         if (coop && rc.jit->chainback_alt)
             return reg_jit_launch(rc.jit->chainback_alt, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st,
-                                  reg_chainback_dyn_lds_bytes(rc.K, true));
+                                  reg_chainback_dyn_lds_bytes(rc.K, rc.R, true));
         const unsigned fpb = rc.jit->chainback_frames_per_block;
         return reg_jit_launch(rc.jit->chainback, &a, sizeof(a), (unsigned)((frames + fpb - 1) / fpb), 64, st,
-                              reg_chainback_dyn_lds_bytes(rc.K, false));
+                              reg_chainback_dyn_lds_bytes(rc.K, rc.R, false));
     }
     switch (rc.id) {
         case 0: return reg_launch_chainback<0>(a, tiles, st, coop);

@@ -176,7 +176,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
         {
             std::ofstream f(src);
             f << "#define VIT_REG_JIT_TU 1\n";
-            if (K == 9 && R <= 2) f << "#define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))\n";   // kernels_reg.hpp, reg_update_kernel
+            if (K == 9 || (K == 7 && R == 3)) f << "#define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))\n";   // kernels_reg.hpp, reg_update_kernel
             f << "#include \"" << src_dir << "/kernels_reg.hpp\"\n"
               << "using SP = vit::RegSpec<" << K << ", " << R;
             for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
