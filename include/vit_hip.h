@@ -13,6 +13,7 @@
  *   vit_hip_update_batch      reset() + Decoder::update<sum_t>()  viterbi_decoder_core.h:202-211, viterbi_decoder_scalar.h:29-55
  *   vit_hip_chainback_batch   chainback()                         viterbi_decoder_core.h:214-236
  *   vit_hip_decode_batch      the call pattern reset->update->chainback of examples/run_simple.cpp:76-80
+ *   vit_hip_chainback_batch_ex  the same, naming which of a code's chainback kernels runs (no reference counterpart)
  *   vit_hip_pipeline_*        the same pattern over a stream of batches (the benchmark's loop over frames,
  *                             examples/run_benchmark.cpp:266-282, with its two separately timed phases :272-281) scheduled on
  *                             two or three HIP streams; _set_timing/_get_timing report the two phases per batch
@@ -138,6 +139,12 @@ int vit_hip_update_batch(vit_hip_handle h, const void* d_symbols, size_t frames,
  *   d_bytes_out [frames][ceil(L/8)] ; d_end_state [frames] uint32 or NULL (=> 0) */
 int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
                             const uint32_t* d_end_state, vit_hip_stream_t stream);
+/* the same with the kernel named: VIT_HIP_KERNEL_CHAINBACK (what vit_hip_chainback_batch launches) or
+ * VIT_HIP_KERNEL_CHAINBACK_ALT, the other chainback kernel of the K = 7 / K = 9 register-plan codes (K = 7: the LDS-ring kernel,
+ * 32 registers -- what a pipeline runs BESIDE update waves; K = 9: the cooperative kernel).  Codes with one chainback kernel
+ * ignore the choice.  Results are identical; tests and schedulers use it (there is no environment switch). */
+int vit_hip_chainback_batch_ex(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                               const uint32_t* d_end_state, vit_hip_stream_t stream, int kernel);
 
 /* update over S = L+K-1 steps from state 0, then chainback: both phases enqueued on `stream`. */
 int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t L, void* d_workspace,
@@ -183,11 +190,14 @@ int vit_hip_depuncture_batch(vit_hip_handle h, const void* d_punctured, size_t p
  *     issues a packed instruction every 5.3 cycles, two every 4.5) with the chainbacks beside them on the third stream, at a
  *     higher wave priority than the updates (between two staggered update kernels the chainback would otherwise get the issue
  *     slots both leave over and become the bottleneck; here the fast register-ring kernel serves K = 7 too);
- *   - register plan whose update waves leave no registers for a chainback wave beside two of them (K = 9, R = 4: 368
- *     registers per wave; K = 7, R = 3: 2 x 248 + 32 > 512): ANY batch of more than one wave per SIMD is fed to the kernels as
- *     SUB-BATCHES of one wave per SIMD through the same three-workspace, two-update-stream schedule (timing records and
- *     vit_hip_pipeline_last_workspace are per sub-batch; an error in the middle of a submit() leaves the sub-batches already
- *     enqueued in flight: sync() or destroy the pipeline before touching the buffers);
+ *       K = 7, R = 3 (LTE: update capped at 240, 2 x 240 + 32), K = 7, R = 4 (DAB: 2 x 224 + 32; eight update waves hold 16 KiB
+ *         of LDS each, the chainback ring of these codes is 12 KiB) and K = 9, R = 4 (CDMA 2000: 224 registers with the
+ *         sub-chunk branch-metric fetch, 8 KiB of LDS per wave) take the same schedule;
+ *   - register plan whose update waves leave no registers (or LDS) for a chainback wave beside two of them (no built-in code any
+ *     more; a run-time compiled code whose kernels spill past the caps may): ANY batch of more than one wave per SIMD is fed to
+ *     the kernels as SUB-BATCHES of one wave per SIMD through the same three-workspace, two-update-stream schedule (timing
+ *     records and vit_hip_pipeline_last_workspace are per sub-batch; an error in the middle of a submit() leaves the sub-batches
+ *     already enqueued in flight: sync() or destroy the pipeline before touching the buffers);
  *   - PLAN_LDS2 where the update waves a CU's LDS admits leave the chainback kernel's 24 registers on every SIMD (K = 11, 12,
  *     14, 15: four waves of at most 120; K = 13: three of 144): two workspaces, chainback beside the next update (K = 15,
  *     4096 frames: 51.6 -> 50.2 ms per batch; K = 13, 8192 x 4096: 16.4 -> 16.0);
@@ -208,10 +218,30 @@ typedef struct vit_hip_pipeline_schedule {
     int32_t reserved;
 } vit_hip_pipeline_schedule;
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out);
+/* The supported way to pick a schedule other than the library's (A/B measurements, a host that knows what else shares the GPU):
+ * every field left at its "rule" value keeps what vit_hip_pipeline_create would choose; the result is what
+ * vit_hip_pipeline_get_schedule_v2 reports.  A request the hardware cannot serve (sub-batches for a batch of one wave per SIMD,
+ * three update streams without sub-batches) is ignored field by field, never an error.  `want` == NULL: the rules.
+ * The library reads NO environment variable for its schedules (a build with -DVIT_HIP_EXPERIMENTS does, for scripts/gpu_ab.sh). */
+typedef struct vit_hip_pipeline_options {
+    uint32_t struct_size;            /* sizeof(vit_hip_pipeline_options) in the caller's build */
+    int32_t chainback_overlap;       /* -1 rule; 0 back to back on the update's stream; 1 overlapped whatever the batch size */
+    int32_t update_streams;          /*  0 rule; 1, 2 or 3 update kernels in flight (3 only with sub-batches of one wave per SIMD) */
+    int32_t sub_batches;             /* -1 rule; 0 never split; 1 split batches of more than one wave per SIMD */
+    int32_t workspaces;              /*  0 rule (update_streams + 1); 2..4 */
+    int32_t chainback_small_kernel;  /* -1 rule; 0 the code's stand-alone chainback kernel; 1 its small-footprint kernel (K = 7) */
+    int32_t chainback_wave_priority; /* -1 rule; 0 / 1 */
+} vit_hip_pipeline_options;
+int vit_hip_pipeline_create_ex(vit_hip_handle h, size_t max_frames, size_t L, const vit_hip_pipeline_options* want,
+                               vit_hip_pipeline_t* out);
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
                             const uint32_t* d_end_state, void* done_event);
 int vit_hip_pipeline_sync(vit_hip_pipeline_t p);
 int vit_hip_pipeline_destroy(vit_hip_pipeline_t p);
+/* schedule_bytes = sizeof(vit_hip_pipeline_schedule) in the CALLER's build: at most that many bytes are written, so a binary
+ * built against an older, shorter struct keeps working when the struct grows. */
+int vit_hip_pipeline_get_schedule_v2(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* schedule, size_t schedule_bytes);
+/* legacy entry point: writes the struct as it was when the symbol was introduced (up to and including sub_batch_frames) */
 int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* schedule);
 /* the decision workspace of the most recently submitted (sub-)batch and the frame range of the submitted batch it holds
  * (vit_hip_export_decisions reads the history from it; first_frame / frames may be NULL): valid after a sync() and until the
@@ -248,7 +278,7 @@ typedef struct vit_hip_kernel_resources {
 } vit_hip_kernel_resources;
 #define VIT_HIP_KERNEL_UPDATE 0
 #define VIT_HIP_KERNEL_CHAINBACK 1
-#define VIT_HIP_KERNEL_CHAINBACK_ALT 2   /* the other chainback kernel of K = 7 / 9 (VIT_HIP_CHAINBACK_ALT=1: tests only) */
+#define VIT_HIP_KERNEL_CHAINBACK_ALT 2   /* the other chainback kernel of K = 7 / 9 (vit_hip_chainback_batch_ex) */
 #define VIT_HIP_KERNEL_RESUME 3
 /* the kernel a handle launches for `kernel` (register plan and PLAN_LDS2; VIT_HIP_ERR_UNSUPPORTED for PLAN_LDS) */
 int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out);

@@ -109,8 +109,9 @@ template <size_t constraint_length, size_t code_rate, typename error_t, typename
 class ViterbiDecoder_HIP_Pipeline {
 public:
     using Batch = ViterbiDecoder_HIP_Batch<constraint_length, code_rate, error_t, soft_t>;
-    ViterbiDecoder_HIP_Pipeline(Batch& decoder, size_t max_frames, size_t total_bits) {
-        if (vit_hip_pipeline_create(decoder.hip_handle(), max_frames, total_bits, &m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_create");
+    // `want`: schedule overrides (vit_hip_pipeline_options, struct_size set by the caller); nullptr: the library's rules
+    ViterbiDecoder_HIP_Pipeline(Batch& decoder, size_t max_frames, size_t total_bits, const vit_hip_pipeline_options* want = nullptr) {
+        if (vit_hip_pipeline_create_ex(decoder.hip_handle(), max_frames, total_bits, want, &m_pipe) != VIT_HIP_OK) die("vit_hip_pipeline_create_ex");
     }
     ~ViterbiDecoder_HIP_Pipeline() { vit_hip_pipeline_destroy(m_pipe); }
     ViterbiDecoder_HIP_Pipeline(const ViterbiDecoder_HIP_Pipeline&) = delete;
@@ -130,7 +131,7 @@ public:
     // which schedule the library chose for max_frames: workspaces, update kernels in flight, chainback overlap
     vit_hip_pipeline_schedule schedule() const {
         vit_hip_pipeline_schedule s;
-        if (vit_hip_pipeline_get_schedule(m_pipe, &s) != VIT_HIP_OK) die("vit_hip_pipeline_get_schedule");
+        if (vit_hip_pipeline_get_schedule_v2(m_pipe, &s, sizeof(s)) != VIT_HIP_OK) die("vit_hip_pipeline_get_schedule_v2");
         return s;
     }
     // per-batch kernel durations (HIP events on the kernels' own streams), the way the reference times update and chainback

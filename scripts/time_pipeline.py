@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
-"""time the decode pipeline (vit_hip_pipeline_*) for ANY code: experiments on schedules (the VIT_HIP_PIPELINE_* switches).
-usage: time_pipeline.py K R G0,G1[,..] decode_type frames L [steps]        (polynomials in decimal or 0o.. octal)"""
+"""time the decode pipeline (vit_hip_pipeline_*) for ANY code; schedule experiments through vit_hip_pipeline_create_ex.
+usage: time_pipeline.py K R G0,G1[,..] decode_type frames L [steps] [option=value ...]   (polynomials in decimal or 0o.. octal)
+options (vit_hip_pipeline_options fields): chainback_overlap= update_streams= sub_batches= workspaces= chainback_small_kernel=
+chainback_wave_priority=      e.g.  time_pipeline.py 7 3 91,117,121 SOFT16 65536 8192 12 sub_batches=1"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from viterbidecodercpp_amd import BatchDecoder, DecodePipeline, ViterbiBranchTable, ViterbiDecoder_Config, get_decoding_config
+from viterbidecodercpp_amd import BatchDecoder, DecodePipeline, ViterbiBranchTable, ViterbiDecoder_Config, _lib, get_decoding_config
 from viterbidecodercpp_amd.codes import Code
 
 K, R = int(sys.argv[1]), int(sys.argv[2])
 G = tuple(int(x, 0) for x in sys.argv[3].split(","))
 dt, F, L = sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
-steps = int(sys.argv[7]) if len(sys.argv) > 7 else 12
+steps = int(sys.argv[7]) if len(sys.argv) > 7 and "=" not in sys.argv[7] else 12
+kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[7:] if "=" in a}
 code = Code(f"K{K}", K, R, G)
 pc = get_decoding_config(dt, R)
 table = ViterbiBranchTable(K, R, G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
 dec = BatchDecoder(table, ViterbiDecoder_Config.from_decoder_config(pc))
 tx, sym = dec.synth(F, L, 3.0, seed=1)
 out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
-pipe = DecodePipeline(dec, F, L)
+pipe = DecodePipeline(dec, F, L, options=_lib.VitHipPipelineOptions(**kw) if kw else None)
 s = pipe.schedule
 for _ in range(3):
     pipe.submit(sym, out)

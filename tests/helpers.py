@@ -64,7 +64,7 @@ def gpu_metrics_to_u32(met, error_bytes):
 
 
 def check_batch_against_oracle(oracle, code, decode_type, F, L, ebn0, seed, plan=None, sym=None, n_steps=None,
-                               start_state=None, end_state=None):
+                               start_state=None, end_state=None, chainback_kernel=None):
     import torch
 
     pc, table, config = make_table_config(code, decode_type)
@@ -84,7 +84,7 @@ def check_batch_against_oracle(oracle, code, decode_type, F, L, ebn0, seed, plan
     assert np.array_equal(gpu_metrics_to_u32(met, pc.error_bytes), want["metrics"]), "final metrics differ"
     assert np.array_equal(rs.cpu().numpy().astype(np.uint64), want["renorm_sum"]), "renormalisation sums differ"
     if n_steps == S:
-        out = dec.chainback(F, L, end_state=end_state).cpu().numpy()
+        out = dec.chainback(F, L, end_state=end_state, kernel=chainback_kernel).cpu().numpy()
         bad = np.argwhere(out != want["bytes"])
         assert bad.size == 0, f"chainback bytes differ first at (frame, byte) = {bad[0]} of {len(bad)}"
     torch.cuda.synchronize()

@@ -2,7 +2,8 @@
 """Randomised soak on the GPU box: tests/test_gpu_fuzz.py's comparison (decision words, metrics, renormalisation sums,
 chainback bytes against the oracle) with fresh seeds, for a wall-clock budget.  Every third case also feeds the decoders in
 two chunks through the resumed update (vit_hip_update_batch_resume) and must land on the same results.
-    python tests/soak_fuzz.py [seconds] [first_seed]        (tests/test_gpu_soak.py runs a 45-second slice under pytest)"""
+    python tests/soak_fuzz.py [seconds] [first_seed] [chainback kernel: 1 | 2]   (tests/test_gpu_soak.py runs a 45-second slice under pytest;
+the third argument forces one of the two chainback kernels of the K = 7 / 9 codes through vit_hip_chainback_batch_ex)"""
 import os
 import sys
 import time
@@ -13,7 +14,7 @@ if ROOT not in sys.path:
 import numpy as np
 
 
-def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
+def soak(budget_seconds: float, first_seed: int = 1, progress=None, chainback_kernel=None) -> int:
     """returns the number of (code, width, config) cases checked; raises AssertionError on the first mismatch"""
     import torch
     from oracle import pyoracle
@@ -64,7 +65,7 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
                 else:
                     met, rs = dec.update(d_sym, L, start_state=ss)
                 got_dec = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
-                out = dec.chainback(F, L, end_state=es).cpu().numpy()
+                out = dec.chainback(F, L, end_state=es, kernel=chainback_kernel).cpu().numpy()
                 met = met.cpu().numpy()
                 met = met.view(np.uint16) if width == 2 else met
                 for f in range(F):
@@ -83,5 +84,6 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None) -> int:
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    total = soak(budget, seed0, progress=lambda m: print(m, flush=True))
+    kern = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    total = soak(budget, seed0, progress=lambda m: print(m, flush=True), chainback_kernel=kern)
     print(f"soak ok: {total} random (code, width, config) cases from seed {seed0}")

@@ -116,18 +116,24 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
     assert valu <= 600 and "v_readfirstlane" not in text, valu
 
 
-@pytest.mark.parametrize("reg_id", [3, 4])
-def test_k9_update_kernels_do_not_spill(tmp_path, reg_id):
-    """K = 9 (64 metric registers per lane): CDMA IS-95A must fit two waves per SIMD (256 registers) and CDMA 2000 one, both
-    without scratch -- the chunked decision gather in reg_update_body is what makes room."""
-    _, usage = _compile("reg_inst.hip", [f"-DVIT_REG_ID={reg_id}"], tmp_path)
+@pytest.mark.parametrize("reg_id,cb_alloc,cb_lds,upd_lds", [(3, 24, 40960, 4096), (4, 24, 40960, 8192), (1, 32, 24576, 12288), (2, 32, 12288, 16384)])
+def test_update_kernels_leave_room_for_a_chainback_wave(tmp_path, reg_id, cb_alloc, cb_lds, upd_lds):
+    """CDMA IS-95A, CDMA 2000 (K = 9: 64 metric registers per lane; the chunked decision gather and -- at R = 4 -- the sub-chunk
+    branch-metric fetch make room), LTE and DAB: two update waves per SIMD without scratch, at most 240 registers each (capped:
+    amdgpu_num_vgpr(120)), so that they leave the chainback kernel of the overlapped schedule its registers; and eight update
+    waves plus two chainback workgroups fit a CU's 160 KiB of LDS (vit_hip_pipeline_create, rule 3; round 4: CDMA 2000 allocated
+    368 registers, LTE 248, DAB 16 + 24 KiB)."""
+    text, usage = _compile("reg_inst.hip", [f"-DVIT_REG_ID={reg_id}"], tmp_path)
     upd = [k for k in usage if "reg_update_kernel" in k]
     assert len(upd) == 2
     for k in upd:
         assert usage[k]["ScratchSize"] == 0, (k, usage[k])
-        if reg_id == 3:
-            # capped at 240 (amdgpu_num_vgpr(120)): two update waves leave 32 registers of a SIMD's 512 for the chainback
-            assert usage[k]["alloc"] <= 240, (k, usage[k])
+        assert usage[k]["alloc"] <= 240 and usage[k].get("AGPRs", 0) == 0, (k, usage[k])
+        assert 2 * usage[k]["alloc"] + cb_alloc <= 512
+        assert usage[k]["lds_static"] == upd_lds, (k, usage[k])
+        assert 8 * usage[k]["lds_static"] + 2 * cb_lds <= 160 * 1024
+    cb = [k for k in usage if ("reg_chainback_kernel" if reg_id >= 3 else "reg_chainback_alt_kernel") in k]
+    assert len(cb) == 1 and usage[cb[0]]["alloc"] <= cb_alloc and usage[cb[0]]["lds_static"] == 0, usage[cb[0]]
 
 
 def test_k9_chainback_streams_rows_through_lds_and_fits_beside_two_update_waves(tmp_path):

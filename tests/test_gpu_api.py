@@ -167,28 +167,29 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     check_batch_against_oracle(oracle, code, decode_type, 33, 104, 2.0, seed=K + R, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
 
 
-@pytest.mark.parametrize("alt", ["0", "1"])
+@pytest.mark.parametrize("alt", [_lib.KERNEL_CHAINBACK, _lib.KERNEL_CHAINBACK_ALT])
 @pytest.mark.parametrize("K,R,G,decode_type", [
     (9, 2, (0o753, 0o561), "SOFT16"),        # CDMA IS-95A, ahead-of-time instantiation
     (9, 4, (0o765, 0o671, 0o513, 0o473), "HARD8"),
     (9, 3, (0o557, 0o663, 0o711), "SOFT8"),  # run-time instantiation
     (7, 2, (0o155, 0o117), "SOFT16"),        # Voyager
+    (7, 4, (0o155, 0o117, 0o123, 0o155), "SOFT16"),   # DAB Radio: its LDS-ring kernel has a two-slot ring (12 KiB)
     (7, 2, (0o171, 0o133), "HARD8"),         # run-time instantiation
 ])
-def test_chainback_bodies(oracle, monkeypatch, K, R, G, decode_type, alt):
+def test_chainback_bodies(oracle, K, R, G, decode_type, alt):
     """K = 7 and K = 9 have two chainback kernels each -- rows streamed through an LDS ring (K = 9: the one in use; K = 7:
     experiments only) and a register-ring / cooperative one (K = 7: the one in use; K = 9: the alternative): both are run here,
     with trace lengths that leave ragged ends above and below the 32-step iterations, frame counts that are no multiple of a
     wave's 128, and per-frame end states."""
-    monkeypatch.setenv("VIT_HIP_CHAINBACK_ALT", alt)
     code = Code(f"K{K}R{R}", K, R, tuple(G))
     rng = np.random.default_rng(R)
     for F, L in ((130, 1000), (70, 384), (33, 104), (257, 40), (1, 24), (3, 8)):
         ss = rng.integers(0, code.num_states, F).astype(np.int32)
         es = rng.integers(0, code.num_states, F).astype(np.int32)
-        check_batch_against_oracle(oracle, code, decode_type, F, L, 2.0, seed=F + L, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
-    check_batch_against_oracle(oracle, code, decode_type, 200, 2048, 1.0, seed=9, plan=_lib.PLAN_REG)
-    check_batch_against_oracle(oracle, code, decode_type, 40, 2048 + 8 * (K + R), 1.0, seed=10, plan=_lib.PLAN_REG)
+        check_batch_against_oracle(oracle, code, decode_type, F, L, 2.0, seed=F + L, plan=_lib.PLAN_REG, start_state=ss, end_state=es,
+                                   chainback_kernel=alt)
+    check_batch_against_oracle(oracle, code, decode_type, 200, 2048, 1.0, seed=9, plan=_lib.PLAN_REG, chainback_kernel=alt)
+    check_batch_against_oracle(oracle, code, decode_type, 40, 2048 + 8 * (K + R), 1.0, seed=10, plan=_lib.PLAN_REG, chainback_kernel=alt)
 
 
 def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tmp_path):
@@ -243,7 +244,9 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 1)),  # K = 13 (144 registers allocated, three waves per SIMD by LDS: 3 x 144 + 24 of 512): overlapped too -- the descriptor rule; 8192 x 4096: 16.4 -> 16.0 ms per batch
     ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 10 (PLAN_LDS): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
-    (6, "SOFT16", 40000, 64, (3, 2, 1)),     # K = 9, R = 4: one update wave takes 360 registers, so the batch goes in sub-batches of 32768
+    (6, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 4: 224 registers with the sub-chunk branch-metric fetch (368 before: sub-batches), 8 KiB of LDS per wave
+    (3, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 7, R = 3 (LTE): update capped at 240 registers: 2 x 240 + 32
+    (4, "SOFT8", 40000, 64, (2, 1, 1)),      # K = 7, R = 4 (DAB): 2 x 224 + 32, eight 16 KiB update waves + two 12 KiB chainback rings per CU
 ])
 def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want):
     """vit_hip_pipeline_*: whatever schedule the library picks (two updates in flight, chainback beside the next update, or
@@ -262,12 +265,12 @@ def test_decode_pipeline_matches_serial_decode(code_id, decode_type, F, L, want)
     pipe = C.c_void_p()
     assert lib.vit_hip_pipeline_create(dec._handle._h, F, L, C.byref(pipe)) == _lib.OK
     sch = _lib.VitHipPipelineSchedule()
-    assert lib.vit_hip_pipeline_get_schedule(pipe, C.byref(sch)) == _lib.OK
+    assert lib.vit_hip_pipeline_get_schedule_v2(pipe, C.byref(sch), C.sizeof(sch)) == _lib.OK
     if want is not None:
         assert (sch.workspaces, sch.update_streams, sch.chainback_overlapped) == want
     sub = int(sch.sub_batch_frames)
     if want is not None:
-        assert sub == (32768 if code_id == 6 else F) and sch.chainback_wave_priority == (1 if sch.update_streams == 2 else 0)
+        assert sub == F and sch.chainback_wave_priority == (1 if sch.update_streams == 2 else 0)
     assert sch.workspace_bytes_each == dec.workspace_bytes(min(F, sub), L)
     assert lib.vit_hip_pipeline_set_timing(pipe, 1) == _lib.OK
     batches, outs = [], []

@@ -74,17 +74,19 @@ def _granule(v):
     return -(-v // 8) * 8
 
 
-@pytest.mark.parametrize("code_index,waves,alt", [(5, 2, False), (2, 2, False), (2, 2, True), (2, 3, True)])
-def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, alt, monkeypatch):
+@pytest.mark.parametrize("code_index,waves,alt", [(5, 2, False), (2, 2, False), (2, 2, True), (2, 3, True),
+                                                  (3, 2, True), (4, 2, True), (6, 2, False)])
+def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, alt):
     """K = 9: the chainback beside TWO update waves per SIMD (2 x 240 + 24 of 512 registers: the shipped schedule);
-    K = 7: the register-ring chainback beside two (2 x 152 + 160), the LDS-ring kernel beside two and beside THREE (3 x 152 + 32)."""
+    K = 7: the register-ring chainback beside two (2 x 152 + 160), the LDS-ring kernel beside two and beside THREE (3 x 152 + 32);
+    LTE (2 x 240 + 32), DAB (2 x 224 + 32 and 8 x 16 KiB + 2 x 12 KiB of LDS per CU), CDMA 2000 (2 x 224 + 24, 8 x 8 KiB + 2 x 40 KiB):
+    the three codes that left the sub-batch schedule in round 5."""
     import torch
 
     dec = _decoder(code_index)
     upd = dec.kernel_resources(_lib.KERNEL_UPDATE)
     cb = dec.kernel_resources(_lib.KERNEL_CHAINBACK_ALT if alt else _lib.KERNEL_CHAINBACK)
     assert waves * upd["vgpr_alloc"] + cb["vgpr_alloc"] <= 512, (upd, cb)          # what the descriptors promise ...
-    monkeypatch.setenv("VIT_HIP_CHAINBACK_ALT", "1" if alt else "0")
     n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     F, L = 32 * n_simd * 2, 256                                                    # a two-waves-per-SIMD batch, short frames
     ws = dec.new_workspace(F, L)
@@ -95,7 +97,7 @@ def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, 
 
     def launch():
         with torch.cuda.stream(s_cb):
-            dec.chainback(F, L, out=out, workspace=ws)
+            dec.chainback(F, L, out=out, workspace=ws, kernel=_lib.KERNEL_CHAINBACK_ALT if alt else _lib.KERNEL_CHAINBACK)
 
     probe = Probe()
     try:
@@ -103,7 +105,7 @@ def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, 
         assert probe.completes_beside(upd["vgpr_alloc"], upd["lds_static_bytes"], waves, launch, s_cb, n_simd), \
             f"the chainback kernel did not run beside {waves} x {upd['vgpr_alloc']}-register waves per SIMD"
         # negative control: the smallest spinner class whose N waves leave LESS than the chainback's allocation
-        too_big = next(v for v in (120, 128, 152, 160, 168, 176, 240, 248, 256) if waves * v + cb["vgpr_alloc"] > 512)
+        too_big = next(v for v in (120, 128, 152, 160, 168, 176, 232, 240, 248, 256) if waves * v + cb["vgpr_alloc"] > 512)
         assert not probe.completes_beside(too_big, upd["lds_static_bytes"], waves, launch, s_cb, n_simd, wait_s=0.5), \
             f"the probe cannot tell: the chainback also ran beside {waves} x {too_big} registers"
     finally:

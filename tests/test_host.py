@@ -18,7 +18,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "vit_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(vit_hip_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(vit_hip_[a-z0-9_]+)\s*\(", header)))
     assert declared == sorted(_lib.EXPORTS)
     lib = _lib.load()
     for name in declared:

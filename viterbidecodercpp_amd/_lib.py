@@ -27,6 +27,7 @@ EXPORTS = [
     "vit_hip_count_bit_errors", "vit_hip_shader_clock_mhz", "vit_hip_pipeline_create", "vit_hip_pipeline_submit", "vit_hip_pipeline_sync",
     "vit_hip_pipeline_destroy", "vit_hip_pipeline_get_schedule", "vit_hip_pipeline_last_workspace", "vit_hip_pipeline_set_timing", "vit_hip_pipeline_get_timing",
     "vit_hip_pipeline_wait_event", "vit_hip_get_kernel_resources", "vit_hip_list_kernels",
+    "vit_hip_chainback_batch_ex", "vit_hip_pipeline_create_ex", "vit_hip_pipeline_get_schedule_v2",
 ]
 
 
@@ -42,6 +43,18 @@ class VitHipPipelineSchedule(C.Structure):
                 ("chainback_wave_priority", C.c_int32), ("overlap_max_frames", C.c_size_t), ("two_updates_max_frames", C.c_size_t),
                 ("workspace_bytes_each", C.c_size_t), ("sub_batch_frames", C.c_size_t),
                 ("chainback_small_kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+class VitHipPipelineOptions(C.Structure):
+    """vit_hip_pipeline_options: every field at its default keeps the library's rule (include/vit_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("chainback_overlap", C.c_int32), ("update_streams", C.c_int32),
+                ("sub_batches", C.c_int32), ("workspaces", C.c_int32), ("chainback_small_kernel", C.c_int32),
+                ("chainback_wave_priority", C.c_int32)]
+
+    def __init__(self, chainback_overlap=-1, update_streams=0, sub_batches=-1, workspaces=0, chainback_small_kernel=-1,
+                 chainback_wave_priority=-1):
+        super().__init__(C.sizeof(VitHipPipelineOptions), chainback_overlap, update_streams, sub_batches, workspaces,
+                         chainback_small_kernel, chainback_wave_priority)
 
 
 class VitHipKernelResources(C.Structure):
@@ -101,6 +114,9 @@ def load():
     L.vit_hip_count_bit_errors.argtypes = [vp, vp, vp, sz, vp, vp]
     L.vit_hip_shader_clock_mhz.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.vit_hip_pipeline_create.argtypes = [vp, sz, sz, C.POINTER(vp)]
+    L.vit_hip_pipeline_create_ex.argtypes = [vp, sz, sz, C.POINTER(VitHipPipelineOptions), C.POINTER(vp)]
+    L.vit_hip_pipeline_get_schedule_v2.argtypes = [vp, C.POINTER(VitHipPipelineSchedule), sz]
+    L.vit_hip_chainback_batch_ex.argtypes = [vp, vp, sz, sz, vp, vp, vp, i32]
     L.vit_hip_pipeline_submit.argtypes = [vp, vp, sz, vp, vp, vp]
     L.vit_hip_pipeline_sync.argtypes = [vp]
     L.vit_hip_pipeline_destroy.argtypes = [vp]

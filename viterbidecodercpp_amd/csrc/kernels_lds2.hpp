@@ -856,11 +856,13 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
                                 (int)GM::smem_bytes) != hipSuccess)
             return -1;
     }
+#ifdef VIT_HIP_EXPERIMENTS
     if (getenv("VIT_HIP_DEBUG")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), GM::T, GM::smem_bytes);
         fprintf(stderr, "lds2_update_kernel<%d>: %d threads, %zu B LDS per workgroup, %d workgroup(s) per CU\n", K, GM::T, GM::smem_bytes, nb);
     }
+#endif
     hipLaunchKernelGGL(kern, dim3(pairs), dim3(GM::T), GM::smem_bytes, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

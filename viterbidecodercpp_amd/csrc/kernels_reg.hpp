@@ -1588,7 +1588,7 @@ __global__ void __launch_bounds__(64, reg_chainback_min_waves<SP>()) reg_chainba
 //         against 163 Gbit/s);
 //  K = 9: the cooperative body (one wave per 32 frames; every q-lane repeats the chase and a ds_bpermute picks the owner's bit:
 //         34 vector instructions per step for 32 frames, 136 registers allocated).  Level with the ring body alone on the device,
-//         no use beside two update waves; tests only (VIT_HIP_CHAINBACK_ALT=1).
+//         no use beside two update waves; tests only (vit_hip_chainback_batch_ex).
 template <class SP>
 VIT_DEV void reg_chainback_alt_body(const RegChainbackArgs& a) {
     if constexpr (SP::NREG == 64) reg_chainback_coop_body<SP>(a);                              // 32 frames per wave
@@ -1830,7 +1830,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
 }
 
 // `prefer_alt`: launch the code's OTHER chainback kernel (K = 7: the LDS-ring body, 32 registers -- what the pipeline asks for
-// when the chainback shares SIMDs with update waves; K = 9: the cooperative body).  VIT_HIP_CHAINBACK_ALT=0|1 overrides (tests).
+// when the chainback shares SIMDs with update waves; K = 9: the cooperative body): vit_hip_chainback_batch_ex picks it.
 inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, size_t L, uint8_t* d_out, const uint32_t* d_end,
                          hipStream_t st, unsigned wave_priority = 0, bool prefer_alt = false) {
     if (frames == 0 || L == 0) return 0;
@@ -1845,7 +1845,9 @@ inline int reg_chainback(const RegCode& rc, const void* d_ws, size_t frames, siz
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     // K = 7, 9: the other chainback kernel of the code (reg_chainback_alt_body)
     bool coop = prefer_alt && (rc.K == 9 || rc.K == 7);
-    if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';
+#ifdef VIT_HIP_EXPERIMENTS
+    if (const char* e = getenv("VIT_HIP_CHAINBACK_ALT")) coop = (rc.K == 9 || rc.K == 7) && *e == '1';   // A/B builds only
+#endif
     if (rc.jit) {
         if (coop && rc.jit->chainback_alt)
             return reg_jit_launch(rc.jit->chainback_alt, &a, sizeof(a), rc.K == 9 ? tiles : (unsigned)((frames + 127) / 128), 64, st,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <math.h>
@@ -522,8 +523,9 @@ int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t 
                              d_metrics_inout, d_metrics_inout, d_renorm_sum, nullptr, stream);
 }
 
+// alt_kernel: the code's other chainback kernel (K = 7: the LDS-ring body, K = 9: the cooperative one); ignored by codes with one
 static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
-                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority, bool small_footprint = false) {
+                                const uint32_t* d_end_state, vit_hip_stream_t stream, unsigned wave_priority, bool alt_kernel = false) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (frames == 0 || L == 0) return VIT_HIP_OK;
     if (!d_workspace || !d_bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "d_workspace/d_bytes_out is NULL");
@@ -531,8 +533,7 @@ static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (h->plan == VIT_HIP_PLAN_REG) {
-        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority,
-                                          small_footprint && h->K == 7);
+        const int rc = vit::reg_chainback(h->reg_code, d_workspace, frames, L, d_bytes_out, d_end_state, st, wave_priority, alt_kernel);
         if (rc != 0) return fail(VIT_HIP_ERR_RUNTIME, "register-plan chainback launch failed");
         return VIT_HIP_OK;
     }
@@ -547,6 +548,13 @@ static int chainback_batch_impl(vit_hip_handle h, const void* d_workspace, size_
 int vit_hip_chainback_batch(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
                             const uint32_t* d_end_state, vit_hip_stream_t stream) {
     return chainback_batch_impl(h, d_workspace, frames, L, d_bytes_out, d_end_state, stream, 0);
+}
+
+int vit_hip_chainback_batch_ex(vit_hip_handle h, const void* d_workspace, size_t frames, size_t L, uint8_t* d_bytes_out,
+                               const uint32_t* d_end_state, vit_hip_stream_t stream, int kernel) {
+    if (kernel != VIT_HIP_KERNEL_CHAINBACK && kernel != VIT_HIP_KERNEL_CHAINBACK_ALT)
+        return fail(VIT_HIP_ERR_INVALID_ARG, "kernel must be VIT_HIP_KERNEL_CHAINBACK or VIT_HIP_KERNEL_CHAINBACK_ALT");
+    return chainback_batch_impl(h, d_workspace, frames, L, d_bytes_out, d_end_state, stream, 0, kernel == VIT_HIP_KERNEL_CHAINBACK_ALT);
 }
 
 int vit_hip_decode_batch(vit_hip_handle h, const void* d_symbols, size_t frames, size_t L, void* d_workspace,
@@ -653,9 +661,40 @@ hipEvent_t pipe_event(vit_hip_pipeline* p) {
 
 extern "C" {
 
-static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
+#ifdef VIT_HIP_EXPERIMENTS
+// A/B builds only (make EXPERIMENTS=1; scripts/gpu_ab.sh): the environment fills whatever the caller's options left to the rules.
+// The shipped library has no such switch: vit_hip_pipeline_create_ex is the supported override.
+static void pipeline_options_from_env(vit_hip_pipeline_options* o) {
+    auto flag = [](const char* name, int32_t* v, int32_t unset) {
+        const char* e = getenv(name);
+        if (e && *v == unset && (*e == '0' || *e == '1')) *v = *e - '0';
+    };
+    flag("VIT_HIP_PIPELINE_OVERLAP", &o->chainback_overlap, -1);
+    flag("VIT_HIP_PIPELINE_SPLIT", &o->sub_batches, -1);
+    flag("VIT_HIP_PIPELINE_CB_SMALL", &o->chainback_small_kernel, -1);
+    flag("VIT_HIP_PIPELINE_CB_PRIO", &o->chainback_wave_priority, -1);
+    if (const char* e = getenv("VIT_HIP_PIPELINE_UPDATES")) if (o->update_streams == 0 && *e >= '1' && *e <= '3') o->update_streams = *e - '0';
+    if (const char* e = getenv("VIT_HIP_PIPELINE_WS")) if (o->workspaces == 0 && *e >= '2' && *e <= '4') o->workspaces = *e - '0';
+}
+#endif
+
+static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, size_t L, const vit_hip_pipeline_options* want,
+                                        vit_hip_pipeline_t* out) {
     if (!h || !out || max_frames == 0) return fail(VIT_HIP_ERR_INVALID_ARG, "bad pipeline arguments");
     *out = nullptr;
+    // the caller's options, read up to the size its build knows; anything beyond stays at "rule"
+    vit_hip_pipeline_options opt{(uint32_t)sizeof(vit_hip_pipeline_options), -1, 0, -1, 0, -1, -1};
+    if (want) {
+        if (want->struct_size < 2 * sizeof(uint32_t)) return fail(VIT_HIP_ERR_INVALID_ARG, "vit_hip_pipeline_options.struct_size is not set");
+        memcpy(&opt, want, want->struct_size < sizeof(opt) ? want->struct_size : sizeof(opt));
+        if (opt.chainback_overlap < -1 || opt.chainback_overlap > 1 || opt.update_streams < 0 || opt.update_streams > 3 ||
+            opt.sub_batches < -1 || opt.sub_batches > 1 || (opt.workspaces != 0 && (opt.workspaces < 2 || opt.workspaces > 4)) ||
+            opt.chainback_small_kernel < -1 || opt.chainback_small_kernel > 1 || opt.chainback_wave_priority < -1 || opt.chainback_wave_priority > 1)
+            return fail(VIT_HIP_ERR_INVALID_ARG, "vit_hip_pipeline_options: field out of range");
+    }
+#ifdef VIT_HIP_EXPERIMENTS
+    pipeline_options_from_env(&opt);
+#endif
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
     vit_hip_pipeline* p = new (std::nothrow) vit_hip_pipeline();
@@ -682,14 +721,15 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         if (per_wave > 0 && h->K == 7 && vit::reg_chainback_fits_beside_updates(h->reg_code, h->shift, 3, true)) p->overlap_max_frames = 3 * per_wave;
         // PLAN_LDS2 codes whose update kernel is capped at 120 registers: the 24-register chainback fits beside four of its waves
         if (h->plan == VIT_HIP_PLAN_LDS2 && vit::lds2_chainback_fits_beside_update(h->K, h->R, h->shift)) p->overlap_max_frames = (size_t)-1;
-        if (const char* o = getenv("VIT_HIP_PIPELINE_OVERLAP")) p->overlap_max_frames = *o == '1' ? (size_t)-1 : *o == '0' ? 0 : p->overlap_max_frames;   // experiments only
-        const char* e = getenv("VIT_HIP_PIPELINE_UPDATES");     // experiments only: force 1 or 2 update streams
-        if (e && (*e == '1' || *e == '2')) p->two_updates_max_frames = *e == '2' ? p->overlap_max_frames : 0;
+        if (opt.chainback_overlap >= 0) p->overlap_max_frames = opt.chainback_overlap ? (size_t)-1 : 0;
+        if (opt.update_streams == 1) p->two_updates_max_frames = 0;                        // never two updates in flight
+        if (opt.update_streams >= 2) p->two_updates_max_frames = p->overlap_max_frames;    // wherever the chainback is overlapped
     }
-    // Rule 3 -- sub-batches.  Where two update waves leave no registers (or LDS) for a chainback wave (K = 9, R = 4: one update
-    // wave allocates 368; K = 7, R = 3: 2 x 248 + 32; K = 7, R = 4: 8 x 16 KiB of LDS), the chainback of a two-waves-per-SIMD
-    // batch cannot run beside the next update at all: any batch of more than one wave per SIMD is fed to the kernels as sub-batches
-    // of one update wave per SIMD from the two update streams (LTE 65536 x 8192: 118 - 120 -> 133 - 145 Gbit/s).
+    // Rule 3 -- sub-batches.  Where two update waves leave no registers (or LDS) for a chainback wave (no built-in code since
+    // round 5: LTE is capped at 240 registers, DAB's chainback ring is 12 KiB, CDMA 2000 fetches its branch metrics in sub-chunks;
+    // a run-time compiled code may still land here), the chainback of a two-waves-per-SIMD batch cannot run beside the next update
+    // at all: any batch of more than one wave per SIMD is fed to the kernels as sub-batches of one update wave per SIMD from the
+    // two update streams (LTE 65536 x 8192, round 3: 118 - 120 -> 133 - 145 Gbit/s).
     p->sub_frames = max_frames;
     p->n_upd = max_frames <= p->two_updates_max_frames ? 2 : 1;
     if (h->plan == VIT_HIP_PLAN_REG && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames &&
@@ -697,24 +737,27 @@ static int vit_hip_pipeline_create_impl(vit_hip_handle h, size_t max_frames, siz
         p->sub_frames = p->two_updates_max_frames;
         p->n_upd = 2;
     }
-    if (const char* e = getenv("VIT_HIP_PIPELINE_SPLIT")) {     // experiments only: 1 forces sub-batches, 0 forbids them
-        if (*e == '1' && p->two_updates_max_frames > 0 && max_frames > p->two_updates_max_frames) { p->sub_frames = p->two_updates_max_frames; p->n_upd = 2; }
-        if (*e == '0' && p->sub_frames < max_frames) { p->sub_frames = max_frames; p->n_upd = 1; }
+    {
+        // one update wave per SIMD, whatever opt.update_streams did to two_updates_max_frames above
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        const size_t per_wave = (h->plan == VIT_HIP_PLAN_REG && cus > 0) ? (size_t)4 * (size_t)cus * (size_t)h->reg_code.tile : 0;
+        if (opt.sub_batches == 1 && per_wave > 0 && max_frames > per_wave) { p->sub_frames = per_wave; p->n_upd = 2; }
+        if (opt.sub_batches == 0 && p->sub_frames < max_frames) { p->sub_frames = max_frames; p->n_upd = 1; }
+        if (opt.update_streams == 3 && per_wave > 0 && p->sub_frames <= per_wave) p->n_upd = 3;   // three update kernels in flight
     }
-    if (const char* e = getenv("VIT_HIP_PIPELINE_UPDATES")) { if (*e == '3' && p->sub_frames <= p->two_updates_max_frames) p->n_upd = 3; }   // experiments only: three update kernels in flight
-    p->n_ws = p->n_upd + 1;
-    if (const char* e = getenv("VIT_HIP_PIPELINE_WS")) { if (*e >= '2' && *e <= '4') p->n_ws = *e - '0'; }   // experiments only
+    p->n_ws = opt.workspaces ? opt.workspaces : p->n_upd + 1;
     // K = 7, chainback beside the update waves of ONE update kernel: the LDS-ring kernel (32 registers, 24 KiB of LDS) leaves
     // the update waves their SIMDs -- 65536 x 8192: 157 -> 160 Gbit/s over the register-ring kernel (160 registers), which stays
     // the kernel of a chainback that runs alone (7 % faster there) and of the two-update schedule (there it runs at the higher wave
     // priority and has to be FAST, not small: hard8 32768 x 8192 163 against 145 Gbit/s)
     p->cb_small = h->plan == VIT_HIP_PLAN_REG && h->K == 7 && p->n_upd == 1;
-    if (const char* e = getenv("VIT_HIP_PIPELINE_CB_SMALL")) p->cb_small = *e == '1';   // experiments only
+    if (opt.chainback_small_kernel >= 0) p->cb_small = opt.chainback_small_kernel == 1 && h->plan == VIT_HIP_PLAN_REG && h->K == 7;
     p->ws_bytes = vit_hip_workspace_bytes(h, p->sub_frames, L);
     p->sym_frame_bytes = (L + (size_t)h->K - 1) * (size_t)h->R * (size_t)h->soft_bytes;
     p->out_frame_bytes = (L + 7) / 8;
     p->cb_wave_priority = p->n_upd > 1 ? 1u : 0u;
-    if (const char* e = getenv("VIT_HIP_PIPELINE_CB_PRIO")) p->cb_wave_priority = *e == '1' ? 1u : 0u;   // experiments only
+    if (opt.chainback_wave_priority >= 0) p->cb_wave_priority = (unsigned)opt.chainback_wave_priority;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
     bool ok = hipStreamCreateWithPriority(&p->s_cb, hipStreamNonBlocking, hi) == hipSuccess;   // the short bit chase gets out of the update's way
@@ -850,8 +893,10 @@ int vit_hip_pipeline_last_workspace(vit_hip_pipeline_t p, void** d_workspace, si
     return VIT_HIP_OK;
 }
 
-int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* s) {
-    if (!p || !s) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+int vit_hip_pipeline_get_schedule_v2(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* out, size_t schedule_bytes) {
+    if (!p || !out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
+    vit_hip_pipeline_schedule full;
+    vit_hip_pipeline_schedule* s = &full;
     memset(s, 0, sizeof(*s));
     s->workspaces = p->n_ws;
     s->update_streams = p->n_upd;
@@ -862,7 +907,13 @@ int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedul
     s->sub_batch_frames = p->sub_frames;
     s->chainback_wave_priority = (int32_t)p->cb_wave_priority;
     s->chainback_small_kernel = (p->cb_small && s->chainback_overlapped) ? 1 : 0;
+    memcpy(out, s, schedule_bytes < sizeof(full) ? schedule_bytes : sizeof(full));
     return VIT_HIP_OK;
+}
+
+int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* s) {
+    // the struct as binaries built against the first header know it: nothing past sub_batch_frames is written
+    return vit_hip_pipeline_get_schedule_v2(p, s, offsetof(vit_hip_pipeline_schedule, sub_batch_frames) + sizeof(size_t));
 }
 
 int vit_hip_pipeline_wait_event(vit_hip_pipeline_t p, void* event) {
@@ -874,7 +925,7 @@ int vit_hip_pipeline_wait_event(vit_hip_pipeline_t p, void* event) {
     return VIT_HIP_OK;
 }
 
-int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out) {
+static int vit_hip_get_kernel_resources_impl(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out) {
     if (!h || !out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     memset(out, 0, sizeof(*out));
     vit::kd::KernelResources r;
@@ -895,7 +946,7 @@ int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_re
     return VIT_HIP_OK;
 }
 
-int vit_hip_list_kernels(size_t index, char* name, size_t name_capacity, vit_hip_kernel_resources* out) {
+static int vit_hip_list_kernels_impl(size_t index, char* name, size_t name_capacity, vit_hip_kernel_resources* out) {
     const vit::kd::Table& t = vit::kd::own_library();
     if (t.empty()) return fail(VIT_HIP_ERR_RUNTIME, "the library's own file could not be read for its kernel descriptors");
     if (index >= t.size()) return fail(VIT_HIP_ERR_INVALID_ARG, "index past the last kernel");
@@ -1250,7 +1301,12 @@ int vit_hip_shader_clock_mhz(int device, double* mhz_out, double* cycles_per_pk_
 }
 
 int vit_hip_pipeline_create(vit_hip_handle h, size_t max_frames, size_t L, vit_hip_pipeline_t* out) {
-    VIT_HIP_NOTHROW(return vit_hip_pipeline_create_impl(h, max_frames, L, out));
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_create_impl(h, max_frames, L, nullptr, out));
+}
+
+int vit_hip_pipeline_create_ex(vit_hip_handle h, size_t max_frames, size_t L, const vit_hip_pipeline_options* want,
+                               vit_hip_pipeline_t* out) {
+    VIT_HIP_NOTHROW(return vit_hip_pipeline_create_impl(h, max_frames, L, want, out));
 }
 
 int vit_hip_pipeline_submit(vit_hip_pipeline_t p, const void* d_symbols, size_t frames, uint8_t* d_bytes_out,
@@ -1264,6 +1320,14 @@ int vit_hip_pipeline_sync(vit_hip_pipeline_t p) {
 
 int vit_hip_pipeline_set_timing(vit_hip_pipeline_t p, int enable) {
     VIT_HIP_NOTHROW(return vit_hip_pipeline_set_timing_impl(p, enable));
+}
+
+int vit_hip_get_kernel_resources(vit_hip_handle h, int kernel, vit_hip_kernel_resources* out) {
+    VIT_HIP_NOTHROW(return vit_hip_get_kernel_resources_impl(h, kernel, out));
+}
+
+int vit_hip_list_kernels(size_t index, char* name, size_t name_capacity, vit_hip_kernel_resources* out) {
+    VIT_HIP_NOTHROW(return vit_hip_list_kernels_impl(index, name, name_capacity, out));
 }
 
 int vit_hip_broadcast_table(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,

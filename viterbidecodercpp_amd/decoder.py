@@ -390,7 +390,9 @@ class BatchDecoder:
             C.c_void_p(rs.data_ptr()), self._stream()))
         return rs
 
-    def chainback(self, frames: int, L: int, end_state=None, out=None, workspace=None):
+    def chainback(self, frames: int, L: int, end_state=None, out=None, workspace=None, kernel=None):
+        """kernel: None (the code's stand-alone chainback kernel) or _lib.KERNEL_CHAINBACK / _lib.KERNEL_CHAINBACK_ALT
+        (vit_hip_chainback_batch_ex: the other chainback kernel of the K = 7 / 9 register-plan codes; same results)"""
         t = self.torch
         ws = self._workspace(frames, L, workspace)
         if out is None:
@@ -398,9 +400,13 @@ class BatchDecoder:
         es = None
         if end_state is not None:
             es = t.as_tensor(end_state, dtype=t.int32, device=self.device).contiguous()
-        _lib.check(_lib.load().vit_hip_chainback_batch(self._handle._h, C.c_void_p(ws.data_ptr()), frames, L,
-                                                       C.c_void_p(out.data_ptr()),
-                                                       C.c_void_p(es.data_ptr()) if es is not None else None, self._stream()))
+        esp = C.c_void_p(es.data_ptr()) if es is not None else None
+        if kernel is None:
+            _lib.check(_lib.load().vit_hip_chainback_batch(self._handle._h, C.c_void_p(ws.data_ptr()), frames, L,
+                                                           C.c_void_p(out.data_ptr()), esp, self._stream()))
+        else:
+            _lib.check(_lib.load().vit_hip_chainback_batch_ex(self._handle._h, C.c_void_p(ws.data_ptr()), frames, L,
+                                                              C.c_void_p(out.data_ptr()), esp, self._stream(), int(kernel)))
         return out
 
     def decode(self, symbols, L: int, out=None, want_metrics=False):
@@ -502,13 +508,18 @@ class DecodePipeline:
     ViterbiDecoder_HIP_Pipeline (include/viterbi_hip/viterbi_decoder_hip_batch.h); the loop it replaces is the reference
     benchmark's per-frame reset -> update -> chainback (examples/run_benchmark.cpp:266-282)."""
 
-    def __init__(self, decoder: BatchDecoder, max_frames: int, L: int):
+    def __init__(self, decoder: BatchDecoder, max_frames: int, L: int, options: "_lib.VitHipPipelineOptions" = None):
+        """options: a _lib.VitHipPipelineOptions to override the library's schedule rules (vit_hip_pipeline_create_ex); None: the rules"""
         self.decoder, self.max_frames, self.L = decoder, int(max_frames), int(L)
         self._p = C.c_void_p()
         with decoder.torch.cuda.device(decoder.device):
-            _lib.check(_lib.load().vit_hip_pipeline_create(decoder._handle._h, self.max_frames, self.L, C.byref(self._p)))
+            if options is None:
+                _lib.check(_lib.load().vit_hip_pipeline_create(decoder._handle._h, self.max_frames, self.L, C.byref(self._p)))
+            else:
+                _lib.check(_lib.load().vit_hip_pipeline_create_ex(decoder._handle._h, self.max_frames, self.L, C.byref(options),
+                                                                  C.byref(self._p)))
         self.schedule = _lib.VitHipPipelineSchedule()
-        _lib.check(_lib.load().vit_hip_pipeline_get_schedule(self._p, C.byref(self.schedule)))
+        _lib.check(_lib.load().vit_hip_pipeline_get_schedule_v2(self._p, C.byref(self.schedule), C.sizeof(self.schedule)))
         # the pipeline runs on private non-blocking streams: these two events order it against torch's streams
         t = decoder.torch
         with t.cuda.device(decoder.device):
