@@ -28,7 +28,7 @@ struct ProbeShared {             // host memory the device can see (hipHostMallo
         if (lds[threadIdx.x] == 0xFFFFFFFFu) sh->pad = 1;                                                                    \
     }
 SPINNER(120, "v119") SPINNER(128, "v127") SPINNER(152, "v151") SPINNER(160, "v159") SPINNER(168, "v167") SPINNER(176, "v175")
-SPINNER(240, "v239") SPINNER(248, "v247") SPINNER(256, "v255")
+SPINNER(216, "v215") SPINNER(224, "v223") SPINNER(232, "v231") SPINNER(240, "v239") SPINNER(248, "v247") SPINNER(256, "v255")
 
 extern "C" {
 
@@ -47,6 +47,7 @@ int probe_spin(void* stream, unsigned blocks, int vgprs, unsigned lds_bytes, Pro
     switch (vgprs) {
         case 120: k = spinner_120; break; case 128: k = spinner_128; break; case 152: k = spinner_152; break;
         case 160: k = spinner_160; break; case 168: k = spinner_168; break; case 176: k = spinner_176; break;
+        case 216: k = spinner_216; break; case 224: k = spinner_224; break; case 232: k = spinner_232; break;
         case 240: k = spinner_240; break; case 248: k = spinner_248; break; case 256: k = spinner_256; break;
         default: return -2;
     }

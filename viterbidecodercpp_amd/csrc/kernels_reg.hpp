@@ -212,6 +212,53 @@ struct RegSpec {
         const bool lsw = A2 == SB - 2;
         return ex1 ? (lsw ? 4 : 1) : ex0 ? (lsw ? 5 : 2) : (lsw ? 3 : 0);
     }
+    // ---- where a step's branch metrics sit in the LDS ring: the LANE BASIS of the step ----
+    // Lane group q of a pair needs E[p ^ x_q] where x_q = q0 a ^ q1 b is linear in the two lane bits (a, b: the patterns the lane
+    // bits contribute in the step's layout).  Written to the ring in pattern order that is a per-lane xor on every read address --
+    // a table of (layout steps x patterns) address registers (48 at K = 7, R = 2; hipcc spilled the 128 of K = 9, R = 4) or one
+    // v_xor in front of every ds_read (CDMA 2000: 28 per step, each stalling its read: 11 % of the kernel).  Instead the PRODUCER
+    // lane writes entry P at index T P, T the change of basis that sends a -> 1 and b -> 2 (bm_basis), so that the readers'
+    // index is T p ^ q: the lane part is q in EVERY step (or one bit of it where a and b are dependent: bm_form), i.e. four
+    // per-lane base addresses for the whole kernel, and T p goes into the instruction's offset field.  The producer pays one
+    // v_xor per pattern and group of four steps (the columns T e_j of its step are per-lane constants).
+    static constexpr u32 lane_pat(int u, u32 q) { return LANE_BITS == 0 ? 0u : X3 ? pat_lane3(u % PER, q) : pat_lane(u % SB, q); }
+    // how the lane bits enter: 0: a, b independent (index ^ q); 1: a == b != 0 (^ q0^q1); 2: b == 0 (^ q0); 3: a == 0 (^ q1); 4: neither
+    static constexpr int bm_form(int u) {
+        const u32 a = lane_pat(u, 1), b = lane_pat(u, 2);
+        return (a != 0 && b != 0 && a != b) ? 0 : (a != 0 && a == b) ? 1 : (a != 0) ? 2 : (b != 0) ? 3 : 4;
+    }
+    static constexpr int bm_form_bits(int f) { return f == 0 ? 2 : f == 4 ? 0 : 1; }      // low index bits the lane part touches
+    struct BmBasis { u32 v[8]; };
+    static constexpr bool bm_in_span(const BmBasis& B, int n, u32 x) {
+        for (u32 m = 0; m < (1u << n); ++m) {
+            u32 sum = 0;
+            for (int k = 0; k < n; ++k) if ((m >> k) & 1u) sum ^= B.v[k];
+            if (sum == x) return true;
+        }
+        return false;
+    }
+    static constexpr BmBasis bm_basis(int u) {
+        BmBasis B{};
+        int n = 0;
+        const u32 a = lane_pat(u, 1), b = lane_pat(u, 2);
+        const int f = bm_form(u);
+        if (f == 0) { B.v[n++] = a; B.v[n++] = b; }
+        else if (f == 1 || f == 2) B.v[n++] = a;
+        else if (f == 3) B.v[n++] = b;
+        for (int j = 0; j < R && n < R; ++j)
+            if (!bm_in_span(B, n, 1u << j)) B.v[n++] = 1u << j;
+        return B;
+    }
+    // T p: the coordinates of pattern p in the basis of layout step u (bit k = coefficient of basis vector k)
+    static constexpr u32 bm_index(int u, u32 p) {
+        const BmBasis B = bm_basis(u);
+        for (u32 c = 0; c < (1u << R); ++c) {
+            u32 sum = 0;
+            for (int k = 0; k < R; ++k) if ((c >> k) & 1u) sum ^= B.v[k];
+            if (sum == p) return c;
+        }
+        return 0;
+    }
     // 64-bit lane mask: lanes whose group q has pattern bit i set in phase ph
     static constexpr uint64_t lane_mask(int ph, int i) {
         uint64_t m = 0;
@@ -344,7 +391,6 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : (U / GROUP) % 2 == 0 ? 2 : (U / GROUP) % 7 == 0 ? 7 : 1);
     constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
     static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
-    constexpr bool RDTAB = SB * NP <= 32;         // read indices per (layout step, pattern) in registers; else per step + one v_xor per read
     constexpr int ROW = NP * 16;                  // uint2 {E, EB} entries per step: [pattern][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
@@ -418,24 +464,33 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             });
         });
     }
-    // LDSBM: ring index (uint2 units) this lane READS pattern p from in phase ph: entry (p ^ pat_lane(ph, q)) of pair g;
-    // and the one it WRITES its own step of a group to (step 4J+q: row q of the group, pattern 0, pair g)
-    u32 rd_idx[LDSBM && RDTAB ? PER : 1][NP], rd_x[LDSBM && !RDTAB ? PER : 1];
-    const u32 wr_idx = q * ROW + g;
+    // LDSBM: byte addresses inside the ring (RegSpec: lane basis).  READ: bm_rd[form][l] = entry (l ^ lane part of the form) of pair
+    // g, the rest of the index is an instruction offset; at most 4 + 2 + 2 + 2 + 1 registers, the forms a code never uses fold
+    // away.  WRITE: its own step of a group (step 4J+q: row q of the group), entry 0 of pair g
+    u32 bm_rd[5][4];
+    const u32 bm_wr = (q * ROW + g) * 8u;
+    // the producer's columns T e_j (x 128 bytes) of ITS step of a group: per-lane constants of the group's place in the layout
+    // period, NCLS places.  Picked out of a packed compile-time constant by shift: written as selects hipcc turned them into
+    // exec-mask branches inside the block loop
+    constexpr int NCLS = LDSBM ? clcm(PER, GROUP) / GROUP : 1;
+    u32 bm_col[NCLS][R];
     if constexpr (LDSBM) {
-        static_for<PER>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int ph = decltype(pc)::value;
-            u32 x;
-            if constexpr (X3) x = q == 0 ? SP::pat_lane3(ph, 0) : q == 1 ? SP::pat_lane3(ph, 1) : q == 2 ? SP::pat_lane3(ph, 2) : SP::pat_lane3(ph, 3);
-            else x = q == 0 ? SP::pat_lane(ph, 0) : q == 1 ? SP::pat_lane(ph, 1) : q == 2 ? SP::pat_lane(ph, 2) : SP::pat_lane(ph, 3);
-            if constexpr (RDTAB) {
-                static_for<NP>([&](auto ppc) __attribute__((always_inline)) {
-                    constexpr u32 p = decltype(ppc)::value;
-                    rd_idx[ph][p] = ((p ^ x) << 4) + g;
-                });
-            } else {
-                rd_x[ph] = (x << 4) | g;          // ((p ^ x) << 4) + g == rd_x ^ (p << 4) because g < 16
-            }
+        static_for<NCLS>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            static_for<R>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr u32 PACK = SP::bm_index((GROUP * c + 0) % PER, 1u << j) | (SP::bm_index((GROUP * c + 1) % PER, 1u << j) << 4) |
+                                     (SP::bm_index((GROUP * c + 2) % PER, 1u << j) << 8) | (SP::bm_index((GROUP * c + 3) % PER, 1u << j) << 12);
+                bm_col[c][j] = ((PACK >> (4u * q)) & 15u) << 7;
+            });
+        });
+        const u32 lane_part[5] = {q, (q ^ (q >> 1)) & 1u, q & 1u, (q >> 1) & 1u, 0u};
+        static_for<5>([&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            static_for<4>([&](auto lc) __attribute__((always_inline)) {
+                constexpr u32 l = decltype(lc)::value;
+                bm_rd[f][l] = (((l ^ lane_part[f]) << 4) + g) * 8u;
+            });
         });
     }
     // LDSBM symbol fetch: the BPS bytes of step 4J+q sit at byte rawX + BPS*q + 4*BPS*J of the tile: NDW dwords from the
@@ -550,8 +605,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     };
     static_assert(U % 2 == 0, "E double buffer alternates per step");
     // LDSBM producer: this lane's step of the group whose first step has ring slot `slot0`, from symbol ring slot `sl`
-    auto bm_produce = [&](auto slot0c, auto slc) __attribute__((always_inline)) {
-        constexpr int slot0 = decltype(slot0c)::value, sl = decltype(slc)::value;
+    // (`gs`: the group's first step as a step of the unrolled block; lane group q makes step gs + q)
+    auto bm_produce = [&](auto gsc, auto slc) __attribute__((always_inline)) {
+        constexpr int gs = decltype(gsc)::value % U, slot0 = gs % RING, sl = decltype(slc)::value;
         u32 wa[NDW - 1], wb[NDW - 1];             // the step's bytes 4k .. 4k+3 of frame A / B
         static_for<NDW - 1>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
@@ -569,14 +625,25 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             A1[i] = pk_max_s(d1, pk_sub(0u, d1));
             A0[i] = pk_max_s(d0, pk_sub(0u, d0));
         });
+        // entry P goes to index T P of the lane's step: the address of P is the xor of the columns bm_col[][j] = T e_j of its set
+        // bits, built from the address of P without its lowest set bit.  waddr[0] is laundered so that hipcc does not hoist the
+        // 2^R - 1 addresses of every group of the period out of the block loop (registers), only the columns stay resident
+        constexpr int cls = (gs % (NCLS * GROUP)) / GROUP;
+        u32 waddr[NP];
+        waddr[0] = bm_wr;
+        if constexpr (NP > 4) asm volatile("" : "+v"(waddr[0]));     // (R <= 2: the nine addresses may stay in registers)
         static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
+            if constexpr (p != 0) {
+                constexpr int j = __builtin_ctz((unsigned)p);
+                waddr[p] = waddr[p & (p - 1)] ^ bm_col[cls][j];
+            }
             u32 e = (p & 1) ? A1[0] : A0[0];
             static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value + 1;
                 e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
             });
-            bm_ring[wr_idx + slot0 * ROW + p * 16] = make_uint2(e, pk_sub(MAXE2, e));
+            *(uint2*)((char*)bm_ring + waddr[p] + slot0 * ROW * 8) = make_uint2(e, pk_sub(MAXE2, e));
         });
         // one wavefront per workgroup: LDS operations of a wave complete in order, so the other lanes' reads that follow
         // in program order see these rows; the fence only keeps the compiler from moving them across
@@ -590,9 +657,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         constexpr int us = un % U, PHn = us % PER, buf = un & 1;
         static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-            u32 idx;
-            if constexpr (RDTAB) idx = rd_idx[PHn][p]; else idx = rd_x[PHn] ^ (u32)(p << 4);
-            const uint2 v = bm_ring[idx + (us % RING) * ROW];
+            constexpr int f = SP::bm_form(PHn), w = SP::bm_form_bits(f);
+            constexpr u32 tp = SP::bm_index(PHn, (u32)p);
+            const uint2 v = *(const uint2*)((const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + (us % RING) * ROW * 8);
             E[buf][p] = v.x;
             EB[buf][p] = v.y;
         });
@@ -606,13 +673,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             if constexpr (RC::first(PHn, h) == h) {
                 constexpr u32 p = RC::pat(PHn, h);
                 constexpr int sl = RC::slot(PHn, h);
-                // byte offset of entry (p ^ x, g): formed HERE, one v_xor_b32 with a literal per read (2.7 clocks: all-VGPR/literal
-                // 32-bit class).  Left to hipcc the 8 x 16 loop-invariant addresses are hoisted out of the block loop and the
-                // kernel spills them (104 bytes of scratch at the 240-register cap); asm volatile keeps the xor where it is
-                static_assert(!BMCHUNK || !RDTAB, "sub-chunk fetches form their addresses from rd_x");
-                u32 off = rd_x[BMCHUNK ? PHn : 0] << 3;
-                if constexpr (p != 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(off) : "n"(p << 7), "v"(off));
-                const uint2 v = *(const uint2*)((const char*)bm_ring + off + (us % RING) * ROW * 8);
+                constexpr int f = SP::bm_form(PHn), w = SP::bm_form_bits(f);
+                constexpr u32 tp = SP::bm_index(PHn, p);
+                const uint2 v = *(const uint2*)((const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + (us % RING) * ROW * 8);
                 Ec[buf][sl] = v.x;
                 EBc[buf][sl] = v.y;
             }
@@ -650,7 +713,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         // first step of block group Jb: produce group Jb + 1, then refill its symbol slot with group Jb + 1 + NG
                         constexpr int Jb = u / GROUP;
                         constexpr int sl = (Jb + 1) % NG;
-                        bm_produce(std::integral_constant<int, (GROUP * (Jb + 1)) % RING>{}, std::integral_constant<int, sl>{});
+                        bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
                         load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
                     }
                     if constexpr (!BMCHUNK) bm_fetch(std::integral_constant<int, u + 1>{});
@@ -900,7 +963,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     // produce group Jb + 1 over it, refill its symbol slot with group Jb + 1 + NG, fetch the new group's first sub-chunk
                     constexpr int Jb = u / GROUP;
                     constexpr int sl = (Jb + 1) % NG;
-                    bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, sl>{});
+                    bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
                     load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
                     bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
                 }
