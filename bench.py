@@ -81,6 +81,10 @@ def parse():
                          "workload); 2 = K9 soft16 65536 x 8192; 3 = K7 hard8, 262144 frames over 8 GPUs = 32768 per GPU "
                          "(--gpus 8 --config 3 is the whole run); 4 = K15 soft16 4096 x 8192.  Sets --code/--decode-type/"
                          "--frames/--bits/--ebn0")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the contract's timed region: an UNTIMED-for-`value` leg of back-to-back submits lasting at least this "
+                         "long with per-batch timing on -> value_sustained, the decimated step series, first/last-100 medians (0: skip)")
+    ap.add_argument("--parity", action="store_true", help="run the in-run parity check against the scalar reference even with --no-cpu-baseline")
     ap.add_argument("--synth", default="hip", choices=["hip", "torch"],
                     help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
     args = ap.parse_args()
@@ -399,7 +403,6 @@ def main():
         # card enters the timed region in the power state the decode itself put it in (with the probe in between, the first eight
         # timed steps ramped from 3.64 to 3.35 ms).  Timing records run through both; the timed region's are the last K.
         clock_cold = shader_clock()
-        clock_before = clock_cold
         pipe.set_timing(True)
         for _ in range(args.warmup):
             pipe.submit(sym, out)
@@ -437,6 +440,74 @@ def main():
 
         def last_decisions(n):            # decision rows of the LAST timed launch, straight from the pipeline's workspace
             return pipe.export_last_decisions(n)
+
+        def sustained_leg(seconds):
+            """>= `seconds` of back-to-back submits (never part of `value`): what a long stream of batches runs at once the card has
+            settled into the decode's own power state.  Submits go out in chunks of ~0.25 s so that the host never queues more than
+            that ahead; per-batch completion times come from the pipeline's own events."""
+            step_ms = float(np.median(step_times))
+            chunk = max(8, int(250.0 / max(step_ms, 0.05)))
+            pipe.set_timing(True)                     # clears the records of the timed region (already read)
+            t_begin = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t_begin < seconds or n < 2 * chunk:
+                for _ in range(chunk):
+                    pipe.submit(sym, out)
+                n += chunk
+                pipe.sync()
+            wall = time.perf_counter() - t_begin
+            u, c, d = pipe.timing()
+            d = d.astype(np.float64)[per_step - 1::per_step]
+            steps_s = np.diff(d)
+            # each chunk ends in a sync: the first step of the next chunk carries the pipeline refill -- excluded from the medians
+            keep = np.ones(len(steps_s), dtype=bool)
+            keep[chunk - 1::chunk] = False
+            st = steps_s[keep]
+            dec = max(1, len(steps_s) // 200)
+            med = float(np.median(st))
+            return {"seconds": wall, "batches": int(n), "submit_chunk": int(chunk),
+                    "ms_per_step_median": med, "ms_per_step_first100_median": float(np.median(st[:100])),
+                    "ms_per_step_last100_median": float(np.median(st[-100:])), "ms_per_step_p10": float(np.percentile(st, 10)),
+                    "ms_per_step_p90": float(np.percentile(st, 90)),
+                    "update_ms_median": float(np.median(u)), "chainback_ms_median": float(np.median(c)),
+                    "ms_per_step_series_decimated": [round(float(x), 3) for x in steps_s[::dec][:256]], "series_decimation": int(dec),
+                    "value_wall_clock": float(F) * L * n / wall / 1e6}
+
+        def update_kernel_clock():
+            """measurement builds only (-DVIT_HIP_CLOCK_STAMPS, VIT_HIP_LIB_PATH): the shader clock the UPDATE WAVES themselves saw
+            (s_memtime against s_memrealtime, lane 0 of every wave, entry to exit) over a few more untimed batches -- beside the
+            chainback of the previous batch, as in the timed region -- and for one update launched alone"""
+            if not hasattr(lib, "vit_hip_experiment_clock_stamps"):
+                return None
+            lib.vit_hip_experiment_clock_stamps.argtypes = [C.c_void_p]
+            tiles = -(-F_launch // tile_frames)
+            wall_khz = 100000.0                        # s_memrealtime: the constant 100 MHz reference clock (hipDeviceAttributeWallClockRate)
+            stamps = torch.zeros((tiles, 6), dtype=torch.int64, device=dev)
+
+            def read(tag):
+                torch.cuda.synchronize()
+                a = stamps.cpu().numpy().astype(np.float64)
+                ok = (a[:, 3] > a[:, 1])
+                a = a[ok]
+                mhz = (a[:, 2] - a[:, 0]) / (a[:, 3] - a[:, 1]) * (wall_khz / 1e3)
+                xcc = a[:, 4].astype(np.int64) & 15
+                t0 = a[:, 1].min()
+                return {"what": tag, "waves": int(len(a)), "mhz_median": float(np.median(mhz)), "mhz_p10": float(np.percentile(mhz, 10)),
+                        "mhz_p90": float(np.percentile(mhz, 90)),
+                        "mhz_median_per_xcd": {int(x): float(np.median(mhz[xcc == x])) for x in sorted(set(xcc.tolist()))},
+                        "wave_lifetime_us_median": float(np.median(a[:, 3] - a[:, 1]) / (wall_khz / 1e3)),
+                        "kernel_span_us": float((a[:, 3].max() - t0) / (wall_khz / 1e3))}
+
+            res = []
+            _lib.check(lib.vit_hip_experiment_clock_stamps(C.c_void_p(stamps.data_ptr())))
+            for _ in range(6):                         # the last update of these runs beside the chainback of the one before
+                pipe.submit(sym, out)
+            pipe.sync()
+            res.append(read("update beside the previous batch's chainback (pipeline, 6 batches; stamps of the last update)"))
+            dec.update(sym[:F_launch], L, want_metrics=False)
+            res.append(read("update alone (one launch, nothing else on the card)"))
+            _lib.check(lib.vit_hip_experiment_clock_stamps(None))
+            return res
 
         def clock_under_load():
             # UNTIMED extra batches with the clock probe launched in their middle: the shader clock while the decode kernels
@@ -492,8 +563,7 @@ def main():
                 done.record(s_cb)
             cb_done[k % NWS] = done
 
-        clock_cold = shader_clock()
-        clock_before = clock_cold             # no probe between warm-up and timed region (see the pipeline route above)
+        clock_cold = shader_clock()             # no probe between warm-up and timed region (see the pipeline route above)
         evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
         for k in range(args.warmup):
             one_step(k)
@@ -515,6 +585,8 @@ def main():
 
         F_launch = F
         clock_under_load = None
+        sustained_leg = None
+        update_kernel_clock = None
 
         def last_decisions(n):
             return 0, dec.export_decisions(n, L, workspace=wss[(args.warmup + args.steps - 1) % NWS])
@@ -536,7 +608,24 @@ def main():
     ber = bit_errors / float(F * L)
 
     # every rank reads its own shader clock under load (untimed extra batches) and says where it was pinned
-    clock_load = clock_under_load() if clock_under_load is not None else (None, None)
+    clock_load = (None, None)
+    if clock_under_load is not None:
+        try:
+            clock_load = clock_under_load()
+        except Exception as e:              # a rank whose probe fails still takes part in the all_gather below
+            clock_load = (None, {"error": f"{type(e).__name__}: {e}"})
+    sustained = None
+    if sustained_leg is not None and args.sustain_seconds > 0:
+        try:
+            sustained = sustained_leg(args.sustain_seconds)
+        except Exception as e:
+            sustained = {"error": f"{type(e).__name__}: {e}"}
+    kernel_clock = None
+    if update_kernel_clock is not None and dec.plan == _lib.PLAN_REG:
+        try:
+            kernel_clock = update_kernel_clock()
+        except Exception as e:
+            kernel_clock = [{"error": f"{type(e).__name__}: {e}"}]
     per_rank_info = None
     if world > 1:
         if affinity and affinity.get("error") and rank == 0:
@@ -548,6 +637,11 @@ def main():
         dist.all_gather(allr, mine)
         per_rank_info = [{"clock_mhz_under_load": float(t[0].item()), "numa_node": int(t[1].item()), "cpus": int(t[2].item()),
                           "pinned_to_gpu_local_cpus": bool(t[3].item() > 0)} for t in allr]
+    sustained_median_all = sustained.get("ms_per_step_median") if sustained else None
+    if world > 1:
+        sm = torch.tensor([sustained_median_all or 0.0], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)
+        sustained_median_all = float(sm[0].item()) or None
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -600,10 +694,16 @@ def main():
         # s_memrealtime around ~2 ms of v_pk_add_u16 on every SIMD: vit_hip_shader_clock_mhz), and the nominal maximum
         # "under_load": a ONE-wave-per-CU probe launched WHILE untimed extra batches run on the pipeline's streams (the
         # batches submitted outlast it: 30 ms of work and more against a probe of a millisecond or two)
-        "clock_mhz": {"before": clock_before[0], "after": clock_after[0], "before_warmup": clock_cold[0],
+        # "before_warmup": the heavy probe on a cold card, before the warm-up (nothing is probed between warm-up and timed region);
+        # "update_kernel": measurement builds only -- the clock the update waves themselves read (s_memtime / s_memrealtime stamps)
+        "clock_mhz": {"before_warmup": clock_cold[0], "after": clock_after[0],
                       "under_load": clock_load[0], "nominal_max_spec": CLOCK_GHZ * 1e3,
-                      "cycles_per_pk_instr_4_waves": [clock_before[1], clock_after[1]],
-                      "under_load_probe": clock_load[1]},
+                      "cycles_per_pk_instr_4_waves": [clock_cold[1], clock_after[1]],
+                      "under_load_probe": clock_load[1], "update_kernel": kernel_clock},
+        # >= --sustain-seconds of back-to-back batches AFTER the timed region (not part of `value`): median step of the whole leg
+        # (max over ranks), its first / last hundred steps, the decimated series
+        "value_sustained": (float(F) * L * world / (sustained_median_all * 1e-3) / 1e6) if sustained_median_all else None,
+        "sustained": sustained,
         "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": upd_bytes_launch, "frames_per_launch": F_launch,
@@ -638,16 +738,21 @@ def main():
         result["roofline_valu"] = {
             "bound": "valu", "kernel": "update", "achieved": ach, "peak": peak_measured, "unit": "G wave-instr/s",
             "frac": ach / peak_measured,
+            # the measured peak is that of a PACKED 16-bit stream; a handful of 32-bit opcodes the kernels also use (v_bitop3 with
+            # VGPR operands, v_xor) issue faster, so it is no strict upper bound for the mix: the guide's 2 clocks per wave64
+            # instruction at the nominal clock is, and is quoted beside it
+            "peak_spec": N_SIMD * CLOCK_GHZ / 2.0, "frac_of_spec": ach / (N_SIMD * CLOCK_GHZ / 2.0),
             "valu_insts_per_launch": valu_insts, "launches_in_flight": NUPD,
             "valu_insts_per_state_update_pair": valu_insts * 64.0 / (state_updates / 2.0),
             "update_waves_per_simd": waves, "ns_per_packed_instr_per_simd_at_that_occupancy": ns[wkey],
-            "shader_clock_mhz_measured_this_run": [clock_before[0], clock_after[0]],
+            "shader_clock_mhz_measured_this_run": [clock_cold[0], clock_after[0]],
             "peak_source": rates["source"], "insts_source": traffic_src}
 
+    if world == 1 and (args.parity or not args.no_cpu_baseline):
+        # parity of the last submitted step's results (the workspace that step wrote)
+        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, last_decisions, sym, out, F, L)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
-        # parity of the last timed step's results (the workspace that step wrote)
-        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, last_decisions, sym, out, F, L)
         result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         if "single_socket_extrapolated_Mbit_s" in result["cpu_baseline"]:
             result["speedup_vs_single_socket_extrapolated"] = value / result["cpu_baseline"]["single_socket_extrapolated_Mbit_s"]

@@ -29,3 +29,24 @@ for k in names:
     print(f"  of wave cycles: VALU active {a.get('SQ_ACTIVE_INST_VALU', 0) / wc:.3f}  wait_any {a.get('SQ_WAIT_ANY', 0) / wc:.3f}  wait_inst_any {a.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}"
           f"  LDS active {a.get('SQ_ACTIVE_INST_LDS', 0) / wc:.3f}  wait_inst_lds {a.get('SQ_WAIT_INST_LDS', 0) / wc:.3f}  VMEM active {a.get('SQ_ACTIVE_INST_VMEM', 0) / wc:.3f}")
     if a.get("SQ_LDS_IDX_ACTIVE"): print(f"  LDS bank conflict cycles / LDS active cycles: {a['SQ_LDS_BANK_CONFLICT'] / a['SQ_LDS_IDX_ACTIVE']:.3f}  (LDS_IDX_ACTIVE {a['SQ_LDS_IDX_ACTIVE']:.4g}, BUSY_CYCLES {a.get('SQ_BUSY_CYCLES', 0):.4g})")
+
+# ---- machine-readable: VALU wave-instructions per wave and trellis step of every update kernel (scripts/matrix.py prices the
+# full-size launches of the benchmark matrix with it: instructions scale with waves x steps) ----
+import json
+meta = {}
+for line in open(os.path.join(root, "sq1.log")) if os.path.exists(os.path.join(root, "sq1.log")) else []:
+    t = line.split()
+    if len(t) >= 6 and t[-2] == "BER":
+        meta[(t[0] if len(t) == 6 else " ".join(t[:-5]), t[-5])] = (int(t[-4]), int(t[-3]))       # (code name, decode type) -> (frames, L)
+out = {}
+for k in names:
+    if "update_kernel" not in k: continue
+    a = {c: acc[k][c] / max(n[k][c], 1) for c in acc[k]}
+    m = re.search(r"RegSpec<(\d+), (\d+),.*?>, (\d+)>", k) or re.search(r"lds2_update_kernel\w*<(\d+), (\d+), (\d+)>", k)
+    if not m: continue
+    if "RegSpec" in k: K, R, shift = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    else: K, shift, R = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    out[f"K{K}|R{R}|shift{shift}|{'reg' if 'RegSpec' in k else 'lds2'}"] = {"kernel": k, "valu_insts": a.get("SQ_INSTS_VALU"), "waves": a.get("SQ_WAVES"),
+                                                                            "lds_insts": a.get("SQ_INSTS_LDS"), "wave_cycles": a.get("SQ_WAVE_CYCLES"),
+                                                                            "valu_active": a.get("SQ_ACTIVE_INST_VALU"), "wait_any": a.get("SQ_WAIT_ANY")}
+json.dump({"frames_L_by_code": {f"{c}|{t}": v for (c, t), v in meta.items()}, "update_kernels": out}, open(os.path.join(root, "valu.json"), "w"), indent=1)

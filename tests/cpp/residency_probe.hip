@@ -27,7 +27,7 @@ struct ProbeShared {             // host memory the device can see (hipHostMallo
             __builtin_amdgcn_s_sleep(32);                                                                                    \
         if (lds[threadIdx.x] == 0xFFFFFFFFu) sh->pad = 1;                                                                    \
     }
-SPINNER(120, "v119") SPINNER(128, "v127") SPINNER(152, "v151") SPINNER(160, "v159") SPINNER(168, "v167") SPINNER(176, "v175")
+SPINNER(120, "v119") SPINNER(128, "v127") SPINNER(136, "v135") SPINNER(144, "v143") SPINNER(152, "v151") SPINNER(160, "v159") SPINNER(168, "v167") SPINNER(176, "v175") SPINNER(184, "v183") SPINNER(192, "v191") SPINNER(200, "v199") SPINNER(208, "v207")
 SPINNER(216, "v215") SPINNER(224, "v223") SPINNER(232, "v231") SPINNER(240, "v239") SPINNER(248, "v247") SPINNER(256, "v255")
 
 extern "C" {
@@ -45,8 +45,9 @@ int probe_free(ProbeShared* p) { return hipHostFree(p) == hipSuccess ? 0 : -1; }
 int probe_spin(void* stream, unsigned blocks, int vgprs, unsigned lds_bytes, ProbeShared* sh, double timeout_s) {
     void (*k)(ProbeShared*, unsigned long long) = nullptr;
     switch (vgprs) {
-        case 120: k = spinner_120; break; case 128: k = spinner_128; break; case 152: k = spinner_152; break;
+        case 120: k = spinner_120; break; case 128: k = spinner_128; break; case 136: k = spinner_136; break; case 144: k = spinner_144; break; case 152: k = spinner_152; break;
         case 160: k = spinner_160; break; case 168: k = spinner_168; break; case 176: k = spinner_176; break;
+        case 184: k = spinner_184; break; case 192: k = spinner_192; break; case 200: k = spinner_200; break; case 208: k = spinner_208; break;
         case 216: k = spinner_216; break; case 224: k = spinner_224; break; case 232: k = spinner_232; break;
         case 240: k = spinner_240; break; case 248: k = spinner_248; break; case 256: k = spinner_256; break;
         default: return -2;

@@ -105,7 +105,7 @@ def test_chainback_wave_becomes_resident_beside_update_waves(code_index, waves, 
         assert probe.completes_beside(upd["vgpr_alloc"], upd["lds_static_bytes"], waves, launch, s_cb, n_simd), \
             f"the chainback kernel did not run beside {waves} x {upd['vgpr_alloc']}-register waves per SIMD"
         # negative control: the smallest spinner class whose N waves leave LESS than the chainback's allocation
-        too_big = next(v for v in (120, 128, 152, 160, 168, 176, 216, 224, 232, 240, 248, 256) if waves * v + cb["vgpr_alloc"] > 512)
+        too_big = next(v for v in (120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224, 232, 240, 248, 256) if waves * v + cb["vgpr_alloc"] > 512)
         assert not probe.completes_beside(too_big, upd["lds_static_bytes"], waves, launch, s_cb, n_simd, wait_s=0.5), \
             f"the probe cannot tell: the chainback also ran beside {waves} x {too_big} registers"
     finally:

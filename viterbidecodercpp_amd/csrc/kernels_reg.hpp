@@ -276,7 +276,10 @@ struct RegSpec {
 // cycles).  All compile time: which butterfly of a sub-chunk is the first to use a pattern, and the register slot it lands in.
 template <class SP>
 struct RegChunk {
-    static constexpr int CS = 4;
+#ifndef VIT_REG_CHUNK_CS
+#define VIT_REG_CHUNK_CS 4
+#endif
+    static constexpr int CS = VIT_REG_CHUNK_CS;
     static constexpr int NSUB = SP::NREG / 2 / CS;
     // (total functions: the generic lambdas that call them are instantiated for every code, also where their results are unused)
     static constexpr int pb(int PH) { return SP::lane_phase(PH % SP::SB) ? SP::T : SP::pbit(PH % SP::SB); }   // classic lane phases only (no X3)
@@ -299,6 +302,11 @@ struct RegChunk {
     }
 };
 
+#ifdef VIT_HIP_CLOCK_STAMPS
+// measurement build only (make EXTRA=-DVIT_HIP_CLOCK_STAMPS; include/vit_hip_experiments.h): lane 0 of every update wave stores
+// s_memtime / s_memrealtime at entry and exit and where it ran -- the shader clock THE UPDATE WAVES saw, per XCD
+inline uint64_t* g_clock_stamps = nullptr;      // [tiles][6] uint64 or null
+#endif
 struct RegUpdateArgs {
     const uint8_t* symbols;
     size_t sym_frame_stride_bytes;
@@ -312,6 +320,9 @@ struct RegUpdateArgs {
     u32 frames;
     u32 t_begin, t_end;     // trellis steps [t_begin, t_end) of every frame; the symbol chunk starts at step t_begin
     DevConfig cfg;
+#ifdef VIT_HIP_CLOCK_STAMPS
+    uint64_t* stamps;
+#endif
 };
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
@@ -379,7 +390,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // per wave at most, so that eight waves still fit a CU (R = 4 with 6 state bits: 8 steps, block of 24)
     // K = 9, R = 3, 4: branch metrics fetched per sub-chunk of four butterflies instead of per step (RegChunk).  Their LDS ring
     // holds ONE group of four steps (8 KiB per wave at R = 4, so that eight update waves and two 40 KiB chainback workgroups share
-    // a CU): the next group is produced at the END of a group's last step, behind the last fetch of the old one
+    // a CU): the next group is produced INSIDE a group's last step, right behind the last fetch of the old one
     constexpr bool BMCHUNK = LDSBM && !SP::X3 && NREG >= 64 && NP >= 8;
     using RC = RegChunk<SP>;
     constexpr int RING = !LDSBM ? 1 : BMCHUNK ? GROUP : (U0 * NP * 128 <= 16384 ? U0 : 8);
@@ -571,7 +582,13 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // computed one step AHEAD, inside the basic block of the previous step's add-compare-select: its dependent chain
     // (perm -> sub -> neg -> max -> add -> sub) then overlaps ACS work instead of stalling the start of every step.
     u32 E[2][BMCHUNK ? 1 : NP], EB[2][BMCHUNK ? 1 : NP];
-    u32 Ec[2][RC::CS], EBc[2][RC::CS];           // BMCHUNK: [sub-chunk parity][slot]
+#ifndef VIT_REG_CHUNK_AHEAD
+#define VIT_REG_CHUNK_AHEAD 1
+#endif
+    constexpr int AHEAD = VIT_REG_CHUNK_AHEAD;   // sub-chunks between a fetch and its use
+    constexpr int NEB = 2 * AHEAD;               // ... and the buffers that takes (a power of two dividing the sub-chunks of a step)
+    static_assert(RC::NSUB % NEB == 0 || !BMCHUNK, "buffer index = sub-chunk % NEB in every step");
+    u32 Ec[NEB][RC::CS], EBc[NEB][RC::CS];       // BMCHUNK: [sub-chunk % NEB][slot]
     auto branch_metrics = [&](auto unc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value;
         constexpr int us = un % U;            // position inside the (current or next) block
@@ -626,12 +643,13 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             A0[i] = pk_max_s(d0, pk_sub(0u, d0));
         });
         // entry P goes to index T P of the lane's step: the address of P is the xor of the columns bm_col[][j] = T e_j of its set
-        // bits, built from the address of P without its lowest set bit.  waddr[0] is laundered so that hipcc does not hoist the
-        // 2^R - 1 addresses of every group of the period out of the block loop (registers), only the columns stay resident
+        // bits, built from the address of P without its lowest set bit.  K = 9 (64 metric registers per lane): waddr[0] is laundered
+        // so that hipcc does not hoist the 2^R - 1 addresses of every group of the period out of the block loop, only the columns
+        // stay resident and the xors run once per group
         constexpr int cls = (gs % (NCLS * GROUP)) / GROUP;
         u32 waddr[NP];
         waddr[0] = bm_wr;
-        if constexpr (NP > 4) asm volatile("" : "+v"(waddr[0]));     // (R <= 2: the nine addresses may stay in registers)
+        if constexpr (BMCHUNK) asm volatile("" : "+v"(waddr[0]));    // (K = 7: registers to spare -- the addresses stay resident, no xor in the loop)
         static_for<NP>([&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
             if constexpr (p != 0) {
@@ -667,7 +685,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // BMCHUNK consumer: the patterns sub-chunk `s` of block step `un` needs (un == U: step 0 of the next block)
     auto bm_fetch_chunk = [&](auto unc, auto sc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value, s = decltype(sc)::value;
-        constexpr int us = un % U, PHn = us % PER, buf = s & 1;
+        constexpr int us = un % U, PHn = us % PER, buf = s % NEB;
         static_for<RC::CS>([&](auto kc) __attribute__((always_inline)) {
             constexpr int h = s * RC::CS + decltype(kc)::value;
             if constexpr (RC::first(PHn, h) == h) {
@@ -685,7 +703,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         static_for<NG>([&](auto sc) __attribute__((always_inline)) { load_group(tb0 + (u32)(decltype(sc)::value * GROUP), sc); });
         bm_produce(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         load_group(tb0 + (u32)(NG * GROUP), std::integral_constant<int, 0>{});
-        if constexpr (BMCHUNK) bm_fetch_chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (BMCHUNK) static_for<AHEAD>([&](auto ac) __attribute__((always_inline)) { bm_fetch_chunk(std::integral_constant<int, 0>{}, ac); });
         else bm_fetch(std::integral_constant<int, 0>{});
     } else {
         branch_metrics(std::integral_constant<int, 0>{});
@@ -801,15 +819,25 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     if constexpr (BMCHUNK && h % RC::CS == 0) {
                         // first butterfly of a sub-chunk: ask for the next sub-chunk's patterns (the last one: for the first of step u + 1)
                         // (the first of a NEW group comes from the produce at the end of this step)
-                        if constexpr (h / RC::CS + 1 < RC::NSUB) bm_fetch_chunk(uc, std::integral_constant<int, h / RC::CS + 1>{});
-                        else if constexpr (u % GROUP != GROUP - 1) bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
+                        if constexpr (h / RC::CS + AHEAD < RC::NSUB) bm_fetch_chunk(uc, std::integral_constant<int, h / RC::CS + AHEAD>{});
+                        else bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, h / RC::CS + AHEAD - RC::NSUB>{});
+                        if constexpr (u % GROUP == GROUP - 1 && h / RC::CS + AHEAD == RC::NSUB - 1) {
+                            // last step of block group Jb and the group's LAST fetch has just been issued (LDS operations of a wave
+                            // complete in order): produce group Jb + 1 over it HERE, in the middle of the step, so that the new
+                            // group's first sub-chunk is fetched a whole sub-chunk ahead like every other (produced at the end of the
+                            // step its fetch sat right in front of its use: an exposed LDS round trip per group)
+                            constexpr int Jb = u / GROUP;
+                            constexpr int sl = (Jb + 1) % NG;
+                            bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
+                            load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     u32 e_p, eb_p;
                     if constexpr (BMCHUNK) {
                         static_assert(RC::r0(PH, h) == r0 && RC::pat(PH, h) == p, "RegChunk mirrors the butterfly enumeration");
-                        e_p = Ec[(h / RC::CS) & 1][RC::slot(PH, h)];
-                        eb_p = EBc[(h / RC::CS) & 1][RC::slot(PH, h)];
+                        e_p = Ec[(h / RC::CS) % NEB][RC::slot(PH, h)];
+                        eb_p = EBc[(h / RC::CS) % NEB][RC::slot(PH, h)];
                     } else {
                         e_p = E[cur][p];
                         eb_p = EB[cur][p];
@@ -954,18 +982,16 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         rsB += (uint64_t)((sub >> 16) >> SHIFT);
                     }
                 }
-                } else if constexpr (BMCHUNK && u % GROUP != GROUP - 1) {
-                    // a step below t_begin of a resumed call: only the look-ahead the skipped butterflies would have issued
-                    bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
-                }
-                if constexpr (BMCHUNK && u % GROUP == GROUP - 1) {
-                    // last step of block group Jb, every fetch of the group issued (LDS operations of a wave complete in order):
-                    // produce group Jb + 1 over it, refill its symbol slot with group Jb + 1 + NG, fetch the new group's first sub-chunk
-                    constexpr int Jb = u / GROUP;
-                    constexpr int sl = (Jb + 1) % NG;
-                    bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
-                    load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
-                    bm_fetch_chunk(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
+                } else if constexpr (BMCHUNK) {
+                    // a step below t_begin of a resumed call: only the look-ahead (and, in a group's last step, the produce) the
+                    // skipped butterflies would have issued
+                    if constexpr (u % GROUP == GROUP - 1) {
+                        constexpr int Jb = u / GROUP;
+                        constexpr int sl = (Jb + 1) % NG;
+                        bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
+                        load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
+                    }
+                    static_for<AHEAD>([&](auto ac) __attribute__((always_inline)) { bm_fetch_chunk(std::integral_constant<int, u + 1>{}, ac); });
                 }
             }
         });
@@ -1612,7 +1638,20 @@ constexpr int reg_update_min_waves() { return 2; }
 #define VIT_REG_UPDATE_VGPR_CAP
 #endif
 template <class SP, int SHIFT>
-__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP reg_update_kernel(RegUpdateArgs a) { reg_update_body<SP, SHIFT, false>(a); }
+__global__ void __launch_bounds__(64, reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP reg_update_kernel(RegUpdateArgs a) {
+#ifdef VIT_HIP_CLOCK_STAMPS
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    reg_update_body<SP, SHIFT, false>(a);
+#ifdef VIT_HIP_CLOCK_STAMPS
+    if (a.stamps && (threadIdx.x & 63) == 0) {
+        uint64_t* st = a.stamps + (size_t)blockIdx.x * 6;
+        st[0] = c0; st[1] = r0; st[2] = __builtin_amdgcn_s_memtime(); st[3] = __builtin_amdgcn_s_memrealtime();
+        st[4] = (uint64_t)__builtin_amdgcn_s_getreg((3 << 11) | 20);      // hwreg(HW_REG_XCC_ID, 0, 4)
+        st[5] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // hwreg(HW_REG_HW_ID): wave, SIMD, CU, SH, SE
+    }
+#endif
+}
 // the resumed update (batched streaming) carries the mid-block entry on top of the throughput kernel's registers: one wave per SIMD
 // is promised, so that no instantiation spills (at two, K = 7 R = 3, 4 took 56 - 168 bytes of scratch per lane and K = 9 R = 2 eight)
 template <class SP, int SHIFT>
@@ -1878,6 +1917,9 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     a.t_begin = (u32)first_step;
     a.t_end = (u32)(first_step + n_steps);
     a.cfg = cfg;
+#ifdef VIT_HIP_CLOCK_STAMPS
+    a.stamps = g_clock_stamps;
+#endif
     const unsigned tiles = (unsigned)reg_tiles(rc, frames);
     if (rc.jit) return reg_jit_launch((d_metrics_in ? rc.jit->resume : rc.jit->update)[shift ? 1 : 0], &a, sizeof(a), tiles, 64, st);
     switch (rc.id) {

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/vit_hip.h"
+#include "../../include/vit_hip_experiments.h"
 #include "kernels_lds.hpp"
 #include "kernels_lds2.hpp"
 #include "kernels_reg.hpp"
@@ -1272,6 +1273,15 @@ int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L
     VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
     return VIT_HIP_OK;
 }
+
+#ifdef VIT_HIP_CLOCK_STAMPS
+// measurement build only (include/vit_hip_experiments.h): every register-plan update launched from now on stamps into d_stamps
+// ([tiles][6] uint64: shader clock and constant clock at entry, at exit, XCC id, HW id); NULL switches it off
+int vit_hip_experiment_clock_stamps(void* d_stamps) {
+    vit::g_clock_stamps = (uint64_t*)d_stamps;
+    return VIT_HIP_OK;
+}
+#endif
 
 // entry points that allocate on the host: no exception crosses the ABI
 #define VIT_HIP_NOTHROW(stmt)                                                                  \
