@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the N-rank set-up without a GPU: rendezvous, broadcast of the table blob, the all-reduce that proves "
+                         "N ranks hold the same decoder, per-rank pinning -- then rank 0 prints the JSON skeleton of the N-rank record "
+                         "(value null) and every rank exits.  With --backend gloo this runs on a CPU-only host.")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
                     help="2: double-buffered decision workspaces, chainback of step i on a second HIP stream beside the "
                          "update of step i+1; 1: both kernels back to back on one stream; 0 (default): the rule of "
@@ -101,7 +105,7 @@ def launch_ranks(args):
 
     n = args.gpus
     have = torch.cuda.device_count()
-    if not args.share_gpu and have < n:
+    if not args.share_gpu and not args.dry_run and have < n:
         sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (use --share-gpu only to rehearse the N>1 path)")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -308,6 +312,54 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
             "chainback_bytes_bit_exact": bool(ok_b), "decision_words_bit_exact": bool(ok_d), "bit_exact": bool(ok_b and ok_d)}
 
 
+def dry_run(args, world, rank, affinity):
+    """--dry-run: everything of the N-rank path that needs no GPU -- process group, blob broadcast, the all-reduce proof, the
+    per-rank gather -- and the skeleton of the record the real run prints (tests/test_dist_cpu.py drives it with 8 gloo ranks)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from viterbidecodercpp_amd import COMMON_CODES, ViterbiBranchTable, ViterbiDecoder_Config, dist as vdist, get_decoding_config, pack_blob
+
+    if args.backend != "gloo":
+        sys.exit("bench.py --dry-run rehearses on the CPU: use --backend gloo")
+    if world > 1:
+        dist.init_process_group("gloo")
+    code = COMMON_CODES[args.code]
+    pc = get_decoding_config(args.decode_type, code.R)
+    blob = None
+    if rank == 0:
+        table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+        blob = pack_blob(table, ViterbiDecoder_Config.from_decoder_config(pc))
+    blob = vdist.broadcast_blob(blob, src=0, device=torch.device("cpu"))
+    blob_sum = int(np.frombuffer(blob, dtype=np.uint8).astype(np.int64).sum())
+    ranks_seen, blob_sum_all = 1, blob_sum
+    per_rank_info = None
+    if world > 1:
+        chk = torch.tensor([1, blob_sum], dtype=torch.int64)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        ranks_seen, blob_sum_all = int(chk[0].item()), int(chk[1].item())
+        mine = torch.tensor([float(rank), float(affinity["numa_node"]) if affinity and affinity["numa_node"] is not None else -1.0,
+                             float(affinity["cpus_used"] or 0) if affinity else 0.0, 1.0 if affinity and affinity["pinned"] else 0.0], dtype=torch.float64)
+        allr = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_info = [{"rank": int(t[0].item()), "numa_node": int(t[1].item()), "cpus": int(t[2].item()),
+                          "pinned_to_gpu_local_cpus": bool(t[3].item() > 0)} for t in allr]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        F, L = args.frames, args.bits
+        print(json.dumps({
+            "dry_run": True, "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
+            "value": None, "unit": "Mbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
+            "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type}, {F} frames x {L} info bits per GPU",
+                       "frames_per_gpu": F, "bits_per_frame": L, "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "global_frames": F * world, "frame_ranges": [[r * F, (r + 1) * F] for r in range(world)],
+            "ranks": {"world_size": world, "ranks_in_blob_allreduce": ranks_seen, "backend": args.backend if world > 1 else None,
+                      "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world, "per_rank": per_rank_info}}))
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -319,15 +371,24 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} from the launcher")
     rank = int(os.environ.get("RANK", "0"))
 
-    if not os.path.exists(os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")):
-        # clean checkout: compile the HIP extension first (there is no other decode path to fall back to)
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    # clean checkout: local rank 0 compiles the HIP extension first (there is no other decode path to fall back to).  The other
+    # local ranks wait for a MARKER that rank 0 writes after the build has RETURNED (the .so exists long before the linker has
+    # finished writing it); the marker is keyed by this launch's rendezvous port, so a stale one from another run is never taken
+    lib_path = os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")
+    marker = os.path.join("/tmp", f"vit_hip_built.{os.getuid()}.{os.environ.get('MASTER_PORT', '0')}.{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        if not os.path.exists(lib_path):
             import __graft_entry__
             __graft_entry__.build()
-        else:
-            while not os.path.exists(os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")):
-                time.sleep(1.0)
-            time.sleep(2.0)
+        if world > 1:
+            with open(marker, "w") as f:
+                f.write(str(os.getpid()))
+    elif not os.path.exists(lib_path) or world > 1:
+        t_wait = time.time()
+        while not os.path.exists(marker):
+            if time.time() - t_wait > 1800:
+                sys.exit("bench.py: local rank 0 never finished building libvit_hip.so")
+            time.sleep(0.2)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -337,6 +398,8 @@ def main():
 
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     affinity = pin_to_gpu_numa_node(local_rank) if world > 1 else None      # before the first GPU call of this rank
+    if args.dry_run:
+        return dry_run(args, world, rank, affinity)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

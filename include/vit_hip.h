@@ -313,9 +313,11 @@ int vit_hip_update_batch_resume(vit_hip_handle h, const void* d_symbols, size_t 
  * the same K, R and widths (template parameters in the reference).  Collective and synchronous on `stream`.  librccl.so is
  * dlopen()ed on first use: the library carries no link-time dependency on RCCL.
  * Failure contract: argument errors are detected alike on every rank before the collective.  A rank whose DATA is bad still
- * enters it (a root that cannot pack or upload the table broadcasts a poisoned header; every rank then returns an error).  A
- * rank that has no device or cannot allocate the <= 96 KiB staging buffer returns VIT_HIP_ERR_NO_DEVICE WITHOUT entering: the
- * caller must then abort the communicator (ncclCommAbort) -- the other ranks are waiting in ncclBroadcast. */
+ * enters it (a root that cannot pack or upload the table broadcasts a poisoned header; every rank then returns an error).  The
+ * 264 KiB device staging buffer is allocated once per device at the process's first call and kept, so a later call cannot run
+ * out of memory in front of the collective.  A rank that has no usable device (hipSetDevice fails, or that one-off allocation
+ * fails at the first call) returns VIT_HIP_ERR_NO_DEVICE WITHOUT entering: the caller must then abort the communicator
+ * (ncclCommAbort) -- the other ranks are waiting in ncclBroadcast. */
 int vit_hip_broadcast_table(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
                             void* branch_table, void* config, int device, vit_hip_stream_t stream);
 

@@ -121,11 +121,14 @@ public:
     }
 
     void reset(size_t starting_state = 0) {
-        // The reference has run (and reported the renormalisation of) every step update() was given: queued steps are run before the
-        // state is dropped, and their sum -- like any sum already computed but not yet returned (a frame shorter than the traceback
-        // buffer whose last calls were flushed by get_error() / chainback()) -- stays owed: the next update() returns it, or the
-        // caller collects it with take_unreported_renormalisation().  Never discarded silently.
+        // A frame's renormalisation never leaks into the next frame's total: whatever is still queued is run (the reference has run
+        // every step update() was given, and the decision rows / metrics stay readable until overwritten), and a sum no update()
+        // call has returned yet is DROPPED here.  That can only be the tail of a frame shorter than the traceback buffer streamed in
+        // short calls (deferred mode; its last calls were flushed by get_error() / chainback() / this reset): a caller who wants
+        // that frame's exact total collects it with take_unreported_renormalisation() BEFORE reset(), or streams in exact mode
+        // (set_exact_update_return), where nothing is ever owed.
         flush_pending();
+        m_unreported_renormalisation = 0;
         m_current_decoded_bit = 0;
         error_t* m = m_metrics.raw_old();
         for (size_t s = 0; s < NUMSTATES; s++) m[s] = m_config.initial_non_start_error;
@@ -186,7 +189,8 @@ public:
         m_unreported_renormalisation += renorm;
     }
     // the renormalisation sum of steps that have been computed but whose sum no update() call has returned yet (deferred mode:
-    // flushes triggered by get_error(), chainback(), reset() or a direct read of the state); collecting it here settles the debt
+    // flushes triggered by get_error(), chainback() or a direct read of the state); collecting it here settles the debt.  The
+    // next update() of the SAME frame returns it otherwise; reset() drops it
     uint64_t take_unreported_renormalisation() {
         const uint64_t v = m_unreported_renormalisation;
         m_unreported_renormalisation = 0;

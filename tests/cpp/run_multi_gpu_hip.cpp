@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#include "viterbi_hip/host_affinity.h"
 #include "viterbi_hip/viterbi_decoder_hip_batch.h"
 #include "test_support.h"
 
@@ -31,9 +32,11 @@ struct RankResult {
     uint64_t noisy_errors = 0;
     double decode_ms = 0;          // wall time of the timed pipeline region (all `steps` batches)
     uint8_t first_tx_byte = 0;
+    viterbi_hip::AffinityResult affinity;   // where the rank's host thread was pinned (the CPUs local to its GPU)
 };
 
 static int rank_main(int rank, int nranks, ncclComm_t comm, size_t frames, size_t L, int steps, RankResult* res) {
+    res->affinity = viterbi_hip::pin_thread_to_gpu_cpus(rank);      // before this thread's first GPU call, like bench.py's ranks
     HIP_OK(hipSetDevice(rank));
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
@@ -109,9 +112,10 @@ int main(int argc, char** argv) {
     double max_ms = 0;
     for (int r = 0; r < n; r++) {
         const double ber = double(res[r].noisy_errors) / double(frames * L);
-        printf("rank %d: table %s, noise-free shard %s, noisy shard BER %.2e, %d batches in %.3f ms = %.1f Mbit/s\n", r,
+        printf("rank %d: table %s, noise-free shard %s, noisy shard BER %.2e, %d batches in %.3f ms = %.1f Mbit/s; host thread %s to %d CPUs of NUMA node %d%s%s\n", r,
                res[r].table_ok ? "ok" : "BAD", res[r].clean_ok ? "exact" : "WRONG", ber, steps, res[r].decode_ms,
-               double(frames * L) * steps / res[r].decode_ms / 1e3);
+               double(frames * L) * steps / res[r].decode_ms / 1e3, res[r].affinity.pinned ? "pinned" : "NOT pinned", res[r].affinity.cpus_used,
+               res[r].affinity.numa_node, res[r].affinity.error.empty() ? "" : ": ", res[r].affinity.error.c_str());
         ok = ok && res[r].rc == 0 && res[r].table_ok && res[r].clean_ok && ber > 0 && ber < 2e-3;
         max_ms = res[r].decode_ms > max_ms ? res[r].decode_ms : max_ms;
     }

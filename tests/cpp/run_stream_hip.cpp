@@ -107,8 +107,8 @@ int main(int argc, char** argv) {
         if (!ok) printf("exact-mode check failed\n");
     }
     // a frame SHORTER than the traceback buffer, streamed at N = R in the default (deferred) mode: the last calls stay queued, the
-    // flush comes from get_error() -- its sum is owed, not lost: take_unreported_renormalisation() collects it, and if nobody
-    // does, reset() keeps it for the next update() call
+    // flush comes from get_error() -- its sum is owed to the SAME frame: take_unreported_renormalisation() collects it; reset()
+    // drops it, so that the next frame's total starts from zero (the reference's `reset(); err = 0; err += update(...)` pattern)
     {
         Core shorty(branch_table, setup.config);
         shorty.set_traceback_length(total_input_bits + 777);
@@ -122,9 +122,11 @@ int main(int argc, char** argv) {
                 acc += shorty.take_unreported_renormalisation();
                 ok = ok && acc == acc_once && acc + e == err_once;
             } else {
-                shorty.reset();                                                     // the debt survives the reset ...
-                acc += Decoder::template update<uint64_t>(shorty, symbols.data(), R);   // ... and the next call pays it
-                ok = ok && acc == acc_once;
+                shorty.reset();                                                     // the debt does NOT survive the reset:
+                const uint64_t first = Decoder::template update<uint64_t>(shorty, symbols.data(), R);
+                (void)shorty.get_error();                                           // (run the queued step)
+                ok = ok && first + shorty.take_unreported_renormalisation() == 0;   // one step from reset renormalises nothing
+                ok = ok && acc <= acc_once;                                         // what the dropped tail held is simply not reported
             }
         }
         if (!ok) printf("short-frame check failed\n");

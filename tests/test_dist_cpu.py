@@ -82,3 +82,25 @@ def test_two_rank_gloo_shard_broadcast_gather(tmp_path, oracle):
     _, sym = synth.make_frames_numpy(code, pc, frames, L, 3.0, seed=77)
     want, _, _ = oracle.decode_frames(code.K, code.R, code.G, pyoracle.stock_config(pyoracle.SOFT16, code.R), sym, L)
     assert np.array_equal(got, want)
+
+
+def test_bench_launcher_dry_run_with_eight_gloo_ranks():
+    """bench.py's own launch_ranks (the `python bench.py --gpus N` form) with EIGHT ranks on the CPU: rendezvous on 127.0.0.1, the
+    build marker, the blob broadcast, the all-reduce that proves eight ranks hold the same decoder, the per-rank gather -- and the
+    skeleton of the 8-rank record (BASELINE configs[3]: 262144 hard-decision frames, 32768 per rank, contiguous shards)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run", "--config", "3"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # rank 0 only
+    r = json.loads(lines[0])
+    assert r["dry_run"] and r["value"] is None and r["n_gpus"] == 8 and r["scaling"] == "weak"
+    assert r["ranks"]["ranks_in_blob_allreduce"] == 8 and r["ranks"]["blob_checksum_identical_on_all_ranks"]
+    assert [x["rank"] for x in r["ranks"]["per_rank"]] == list(range(8))
+    assert r["global_frames"] == 262144 and r["frame_ranges"][0] == [0, 32768] and r["frame_ranges"][7] == [229376, 262144]
+    assert all(a[1] == b[0] for a, b in zip(r["frame_ranges"], r["frame_ranges"][1:]))     # contiguous, disjoint shards

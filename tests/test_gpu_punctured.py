@@ -104,8 +104,8 @@ def test_streaming_exact_return_mode_and_short_frames(oracle, decode_type):
     """(1) set_exact_update_return(True): every N = R call returns what the reference's update() returns for THAT call
     (examples/helpers/puncture_code_helpers.h:51 accumulates per call) -- checked call by call against the oracle streamed the
     same way.  (2) default (deferred) mode with a frame SHORTER than the traceback buffer: the flush comes from get_error(),
-    its renormalisation sum is owed -- collected by take_unreported_renormalisation(), or kept across reset() for the next
-    update(): never dropped (round-3 advisor finding)."""
+    its renormalisation sum is owed to THAT frame -- collected by take_unreported_renormalisation(); reset() drops it, so the next
+    frame's total starts from zero (round-4 advisor finding: a carried debt inflated the next frame's error metric)."""
     code = COMMON_CODES[4]
     pc = get_decoding_config(decode_type, code.R)
     table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
@@ -146,7 +146,10 @@ def test_streaming_exact_return_mode_and_short_frames(oracle, decode_type):
         assert err == whole["error"]
         if collect:
             acc += short.take_unreported_renormalisation()
+            assert acc == whole["renorm_sum"]
         else:
-            short.reset()
-            acc += ViterbiDecoder_HIP.update(short, flat[:code.R])     # the next call pays the debt
-        assert acc == whole["renorm_sum"]
+            short.reset()                                   # the tail's sum is dropped, not carried into the next frame
+            first = ViterbiDecoder_HIP.update(short, flat[:code.R])
+            short.get_error()
+            assert first + short.take_unreported_renormalisation() == per_call[0]
+            assert acc <= whole["renorm_sum"]

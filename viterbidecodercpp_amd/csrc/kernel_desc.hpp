@@ -68,6 +68,7 @@ inline bool parse_code_object(const uint8_t* p, size_t n, Table& out) {
         if (st.type != 2 /* SHT_SYMTAB */) continue;           // .symtab holds every kernel's descriptor symbol (.dynsym only the exported ones)
         if (st.link >= sec.size() || st.entsize < 24) continue;
         const Section& str = sec[st.link];
+        if (str.type == 8 /* SHT_NOBITS: no bytes in the file, its offset / size were never range-checked */) continue;
         for (uint64_t o = 0; o + st.entsize <= st.size; o += st.entsize) {
             const uint8_t* s = p + st.off + o;
             const uint32_t name_off = rd32(s);
@@ -78,6 +79,7 @@ inline bool parse_code_object(const uint8_t* p, size_t n, Table& out) {
             const size_t len = strnlen(name, (size_t)(str.size - name_off));
             if (len < 4 || memcmp(name + len - 3, ".kd", 3) != 0) continue;
             const Section& home = sec[shndx];
+            if (home.type == 8 /* SHT_NOBITS */) continue;
             if (value < home.addr || value - home.addr + 64 > home.size) continue;
             const uint8_t* d = p + home.off + (value - home.addr);   // amd_kernel_descriptor_t, 64 bytes
             KernelResources r;
@@ -141,8 +143,10 @@ inline bool parse_file(const std::string& path, Table& out) {
     uint16_t shstrndx = 0;
     if (!elf_sections(p, n, sec, &shstrndx)) return false;
     const Section& names = sec[shstrndx];
+    if (names.type == 8 /* SHT_NOBITS */) return false;
     bool any = false;
     for (const Section& s : sec) {
+        if (s.type == 8 /* SHT_NOBITS */) continue;
         if (s.name >= names.size || strncmp((const char*)p + names.off + s.name, ".hip_fatbin", (size_t)(names.size - s.name)) != 0) continue;
         any = parse_bundles(p + s.off, (size_t)s.size, out) || any;
     }

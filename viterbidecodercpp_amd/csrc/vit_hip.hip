@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1024,19 +1025,35 @@ const RcclApi* rccl_api() {
 }
 }  // namespace
 
+namespace {
+constexpr size_t BROADCAST_STAGING_BYTES = 264 * 1024;      // >= vit_hip_blob_bytes(16, 8, 2, 2)
+struct BroadcastStaging { void* buf[64] = {nullptr}; std::mutex alloc; std::mutex use[64]; };
+BroadcastStaging& broadcast_staging_table() { static BroadcastStaging t; return t; }
+// the calling thread has `device` current (DeviceGuard); nullptr if the device index is out of the table or the one-off hipMalloc fails
+void* broadcast_staging(int device) {
+    if (device < 0 || device >= 64) return nullptr;
+    BroadcastStaging& t = broadcast_staging_table();
+    std::lock_guard<std::mutex> lock(t.alloc);
+    if (!t.buf[device] && hipMalloc(&t.buf[device], BROADCAST_STAGING_BYTES) != hipSuccess) { t.buf[device] = nullptr; (void)hipGetLastError(); }
+    return t.buf[device];
+}
+std::mutex& broadcast_staging_mutex(int device) { return broadcast_staging_table().use[device]; }
+}  // namespace
+
 static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
                             void* branch_table, void* config, int device, vit_hip_stream_t stream) {
     // Argument checks depend only on what every rank passes alike (K, R, widths, pointers being non-NULL): a bad call fails on
     // all ranks the same way and nobody is left waiting in ncclBroadcast.  Past them, a rank enters the collective exactly once
     // whatever happens to its DATA: a root that cannot pack or upload its table broadcasts a poisoned header, which the other
-    // ranks report as an error.  What a rank cannot do is take part without a device or a device buffer: hipSetDevice /
-    // hipMalloc(<= 96 KiB) failing on ONE rank returns VIT_HIP_ERR_NO_DEVICE from that rank BEFORE the collective, and the other
-    // ranks wait in ncclBroadcast until the caller aborts the communicator (ncclCommAbort) -- the usual contract of a rank that
-    // dies in front of a collective; include/vit_hip.h says so.
+    // ranks report as an error.  What a rank cannot do is take part without a device: hipSetDevice failing on ONE rank (or, at
+    // the process's FIRST broadcast on that device only, the one-off hipMalloc of the 264 KiB staging buffer) returns
+    // VIT_HIP_ERR_NO_DEVICE from that rank BEFORE the collective, and the other ranks wait in ncclBroadcast until the caller aborts
+    // the communicator (ncclCommAbort) -- the usual contract of a rank that dies in front of a collective; include/vit_hip.h says so.
     if (!nccl_comm || !branch_table || !config) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     if (K < 2 || K > 16 || R < 1 || R > 8 || !((soft_bytes == 2 && error_bytes == 2) || (soft_bytes == 1 && error_bytes == 1)))
         return fail(VIT_HIP_ERR_UNSUPPORTED, "unsupported (K, R, soft_t, error_t)");
     const size_t need = vit_hip_blob_bytes(K, R, soft_bytes, error_bytes);
+    if (need > BROADCAST_STAGING_BYTES) return fail(VIT_HIP_ERR_UNSUPPORTED, "blob larger than the staging buffer");
     const RcclApi* api = rccl_api();
     if (!api) return fail(VIT_HIP_ERR_RUNTIME, "RCCL not available: ncclBroadcast is neither in the process nor in librccl.so");
     std::vector<uint8_t> blob(need, 0);
@@ -1044,9 +1061,14 @@ static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int
     if (!guard.ok)
         return fail(VIT_HIP_ERR_NO_DEVICE, "hipSetDevice failed on this rank BEFORE the broadcast: abort the communicator, the other ranks are waiting in it");
     hipStream_t st = (hipStream_t)stream;
-    void* d_buf = nullptr;
-    if (hipMalloc(&d_buf, need) != hipSuccess)
-        return fail(VIT_HIP_ERR_NO_DEVICE, "hipMalloc failed on this rank BEFORE the broadcast: abort the communicator, the other ranks are waiting in it");
+    // the staging buffer: allocated ONCE per device, at the first call, for the largest blob the library accepts (K = 16, R = 8,
+    // 16-bit: 256 KiB + header) and kept for the life of the process -- a later broadcast cannot fail in front of the collective
+    // for want of memory; the only pre-collective failure left is a rank without a usable device
+    void* d_buf = broadcast_staging(device);
+    if (!d_buf)
+        return fail(VIT_HIP_ERR_NO_DEVICE, "no staging buffer on this rank's device BEFORE the broadcast (first call: hipMalloc of 264 KiB failed): abort the communicator, the other ranks are waiting in it");
+    // one broadcast at a time per device buffer
+    std::lock_guard<std::mutex> staging_lock(broadcast_staging_mutex(device));
     std::string root_error;
     if (rank == root) {
         if (vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need) != VIT_HIP_OK) {
@@ -1066,7 +1088,6 @@ static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int
     else if (hipMemcpyAsync(blob.data(), d_buf, need, hipMemcpyDeviceToHost, st) != hipSuccess ||
              hipStreamSynchronize(st) != hipSuccess)
         result = fail(VIT_HIP_ERR_RUNTIME, "copying the broadcast blob back failed");
-    (void)hipFree(d_buf);
     if (result != VIT_HIP_OK) return result;
     if (!root_error.empty()) return fail(VIT_HIP_ERR_RUNTIME, "root rank could not pack the table: " + root_error);
     BlobHeader hd;

@@ -183,9 +183,11 @@ class ViterbiDecoder_Core:
         self._exact_update_return = bool(exact)
 
     def reset(self, starting_state: int = 0):
-        # queued steps are run before the state is dropped (the reference has run them and reported their renormalisation); a sum
-        # computed but not yet returned stays owed to the next update() / take_unreported_renormalisation(): never discarded
+        # queued steps are run before the state is dropped (the reference has run them); a renormalisation sum no update() call has
+        # returned yet is DROPPED: a frame's tail never inflates the next frame's total (collect it with
+        # take_unreported_renormalisation() before reset(), or stream in exact mode)
         self.flush_pending()
+        self._unreported = 0
         self.m_current_decoded_bit = 0
         self._metrics[:] = self.m_config.initial_non_start_error
         self._metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
