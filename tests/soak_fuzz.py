@@ -26,6 +26,7 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None, chainback_ke
     cases = [(COMMON_CODES[2], _lib.PLAN_REG), (COMMON_CODES[3], _lib.PLAN_REG), (COMMON_CODES[4], _lib.PLAN_REG),
              (COMMON_CODES[5], _lib.PLAN_REG), (COMMON_CODES[6], _lib.PLAN_REG), (COMMON_CODES[0], _lib.PLAN_REG),
              (COMMON_CODES[1], _lib.PLAN_REG), (Code("K11", 11, 2, (0o3345, 0o3613)), _lib.PLAN_LDS2),
+             (Code("K10", 10, 3, (0o1117, 0o1365, 0o1633)), _lib.PLAN_LDS2),
              (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), _lib.PLAN_LDS2), (COMMON_CODES[7], _lib.PLAN_LDS2),
              (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS), (Code("K16", 16, 2, (46749, 58851)), _lib.PLAN_LDS2)]
     t_end = time.time() + budget_seconds

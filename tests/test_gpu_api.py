@@ -22,8 +22,15 @@ def test_plan_selection_and_errors():
         info = dec._handle.info
         assert list(info.polynomials[:COMMON_CODES[cid].R]) == list(COMMON_CODES[cid].G) and info.table_is_linear == 1
         assert (info.soft_decision_high, info.soft_decision_low) == (127, -127)
-    # K=10 has no register plan (and no LDS2): served by the LDS plan, the others refused
+    # K=10: PLAN_LDS2 since round 5 (no register plan)
     code = Code("custom", 10, 2, (0o1755, 0o1363))
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    assert dec.plan == _lib.PLAN_LDS2
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_LDS) == _lib.OK
+    # K=8, R=3 has neither: served by the LDS plan, the others refused
+    code = Code("custom", 8, 3, (0o367, 0o331, 0o225))
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_LDS
@@ -242,7 +249,8 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     (7, "SOFT16", 24, 256, (2, 1, 1)),       # K = 15 (PLAN_LDS2, update capped at 120 registers): chainback beside the next update
     ((11, 2, (0o3345, 0o3613)), "SOFT16", 40, 128, (2, 1, 1)),    # K = 11: the same
     ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 1)),  # K = 13 (144 registers allocated, three waves per SIMD by LDS: 3 x 144 + 24 of 512): overlapped too -- the descriptor rule; 8192 x 4096: 16.4 -> 16.0 ms per batch
-    ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 10 (PLAN_LDS): back to back
+    ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 1)),   # K = 10 (PLAN_LDS2 since round 5, capped at 120 registers): overlapped
+    ((8, 3, (0o367, 0o331, 0o225)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 8, R = 3 (PLAN_LDS: no register-plan instantiation): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 4: 224 registers with the sub-chunk branch-metric fetch (368 before: sub-batches), 8 KiB of LDS per wave
     (3, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 7, R = 3 (LTE): update capped at 240 registers: 2 x 240 + 32

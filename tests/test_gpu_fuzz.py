@@ -19,6 +19,7 @@ CASES = [
     (COMMON_CODES[4], [_lib.PLAN_REG]),
     (COMMON_CODES[5], [_lib.PLAN_REG, _lib.PLAN_LDS]),
     (COMMON_CODES[6], [_lib.PLAN_REG]),
+    (Code("K10", 10, 2, (0o1167, 0o1545)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
     (Code("K11", 11, 2, (0o3345, 0o3613)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
     (COMMON_CODES[7], [_lib.PLAN_LDS2]),
     # K = 16: one 1024-thread workgroup per CU, 128 KiB of metrics updated in place; the LDS plan reads its patterns from L2

@@ -22,6 +22,7 @@ CASES = [
     (COMMON_CODES[0], "SOFT16", _lib.PLAN_REG, 130, 104),     # K3
     (COMMON_CODES[1], "SOFT8", _lib.PLAN_REG, 130, 104),      # K5
     (K11, "SOFT16", _lib.PLAN_LDS2, 5, 72),
+    (Code("K10", 10, 2, (0o1167, 0o1545)), "SOFT8", _lib.PLAN_LDS2, 5, 96),    # K10: half-filled wavefront
     (COMMON_CODES[7], "SOFT16", _lib.PLAN_LDS2, 3, 40),       # K15
     (Code("K16 R=1/2", 16, 2, (46749, 58851)), "SOFT16", _lib.PLAN_LDS2, 3, 24),
     (K6, "SOFT16", _lib.PLAN_LDS, 4, 88),
@@ -101,6 +102,7 @@ LOW_THR_CASES = [
     (COMMON_CODES[5], 2, _lib.PLAN_REG, 34, 90),       # K9
     (COMMON_CODES[1], 2, _lib.PLAN_REG, 130, 90),      # K5: all states in one lane
     (K11, 2, _lib.PLAN_LDS2, 4, 60),
+    (Code("K10", 10, 2, (0o1167, 0o1545)), 2, _lib.PLAN_LDS2, 4, 60),
     (COMMON_CODES[7], 2, _lib.PLAN_LDS2, 3, 33),       # K15: careful blocks predicted at every block position
     (K6, 2, _lib.PLAN_LDS, 4, 80),
 ]

@@ -1,4 +1,4 @@
-// kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 11..16, any polynomials): one workgroup per frame PAIR,
+// kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 10..16, any polynomials): one workgroup per frame PAIR,
 // state metrics of both frames packed in one u32 per state and double-buffered in LDS, FOUR trellis steps per barrier.
 //
 // Device implementation of the reference's scalar strategy
@@ -147,7 +147,12 @@ struct Lds2Geom {
     static constexpr int G = N / 16;                       // radix-16 groups (= decision dwords per trellis step and frame pair)
     static constexpr int JB = SBITS - 4;                   // bits of a group index
     static constexpr int GPT = G >= 256 ? 2 : 1;           // groups per thread (K >= 13: two, A = tid and B = tid + T)
-    static constexpr int T = G / GPT, NW = T / 64;
+    // thread slots that own groups.  K = 10 has 32 of them: the workgroup is still one full wavefront (the table build wants 64
+    // lanes, one per entry) and lanes 32 - 63 DUPLICATE lanes 0 - 31 -- same loads, same arithmetic, same stores of the same values
+    // to the same addresses -- so that no path of the kernel needs a lane predicate; half the vector unit idles through the
+    // add-compare-select, which still leaves K = 10 at half the per-state rate of its neighbours instead of a twentieth (PLAN_LDS)
+    static constexpr int TG = G / GPT;
+    static constexpr int T = TG < 64 ? 64 : TG, NW = T / 64;
     static constexpr int BLK = 4;                          // trellis steps per block
     static constexpr int CPW = (BLK + NW - 1) / NW;        // tables a wavefront builds per block
     // K = 15: 512 threads and 72 KiB of LDS per workgroup, so that TWO workgroups share a CU (4 waves per SIMD, 128 VGPRs);
@@ -155,7 +160,7 @@ struct Lds2Geom {
     static constexpr int MINW = K >= 15 ? 4 : 2;
     static constexpr size_t tab_bytes = (size_t)2 * BLK * GPT * 64 * 8;
     static constexpr size_t smem_bytes = tab_bytes + 32 * 4 + (size_t)N * 4;
-    static_assert(T >= 64 && T <= 1024, "PLAN_LDS2 serves K = 11..16");
+    static_assert(TG >= 32 && T <= 1024, "PLAN_LDS2 serves K = 10..16");
 };
 
 // One workgroup per frame pair.  The N packed metrics live in ONE LDS buffer that a block of four trellis steps updates IN
@@ -186,6 +191,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     u32* const met = flag + 16;                                // [N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const int gid = tid & (GM::TG - 1);          // the thread's group slot (== tid except at K = 10, where lanes 32 - 63 mirror 0 - 31)
     // the wavefront's index, pinned uniform: everything derived from it (which table it builds, whether it builds one at all)
     // is then scalar control flow and scalar data, not exec-mask branches over vector compares
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,7 +224,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             l2_static_for<2>([&](auto ec) __attribute__((always_inline)) {
                 constexpr int h = 2 * h2 + decltype(ec)::value;
                 constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
-                const u32 lower = lds2_state_of(C - 1, r0, (u32)tid, SBITS);   // top bit clear: butterfly index < H
+                const u32 lower = lds2_state_of(C - 1, r0, (u32)gid, SBITS);   // top bit clear: butterfly index < H
                 // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + SET_TAB, an instruction offset)
                 const u32 off = (u32)C * STEP_TAB + lds2_tab_index((u32)a.pattern[lower] & 63u, a.idx_f[C], a.idx_t[C]) * 8u;
                 pk |= off << (16 * decltype(ec)::value);
@@ -424,7 +430,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // (`high` / `low` stay scalar there: a v_mov per symbol on the four building wavefronts) and the others none -- a register
     // more spills (12 - 28 bytes of scratch, reloads inside the block)
 #ifndef VIT_L2_VECTOR_MASKS
-    constexpr bool CAPPED = K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
+    constexpr bool CAPPED = K == 10 || K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
     constexpr int VECTOR_MASKS = CAPPED ? (RT != 0 ? 2 : 0) : 3;
 #else
     constexpr int VECTOR_MASKS = VIT_L2_VECTOR_MASKS;
@@ -482,8 +488,8 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         u32 row_off = (u32)(C * G);
         asm volatile("" : "+s"(row_off));          // an SGPR whose value the compiler does not know
         u32* const row = wsp + row_off;
-        stage(cc, mA, addr, 0u, row + tid);
-        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + tid);
+        stage(cc, mA, addr, 0u, row + gid);
+        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + gid);
         __builtin_amdgcn_sched_barrier(0);
     };
     // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
@@ -495,13 +501,13 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // (236 bytes of scratch, ~50 reloads per block); re-forming them from the thread index in every block, as round 2 did,
     // cost 27 VALU per block.
     constexpr u32 MET_OFF = (u32)GM::tab_bytes + 32u * 4u;                 // byte offset of met[] inside lds2_smem
-    const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)tid, (u32)N);     // relative to lds2_smem
+    const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)gid, (u32)N);     // relative to lds2_smem
     // the compile-time-rate instantiation has the registers for all four store offsets; the others carry one and form the rest
     // with a v_xor each
     constexpr int NST = RT ? 4 : 1;
     u32 st_off[NST];
 #pragma unroll
-    for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)tid ^ (u32)(q << 1));
+    for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)gid ^ (u32)(q << 1));
     // the offsets are turned into ABSOLUTE LDS addresses once, here (the address of lds2_smem inside the workgroup's LDS is added
     // now, not in every block), and used through explicit address-space-3 pointers; the loop-carried values themselves are made
     // opaque in place (no copy) at each use
@@ -519,7 +525,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         });
     };
     auto load_metrics = [&]() __attribute__((always_inline)) {
-        u32 t = (u32)tid;
+        u32 t = (u32)gid;
         l2_opaque(ld_addr);
         if constexpr (!SEP) l2_opaque(t);
         load_group(mA, t, ld_addr);
@@ -580,7 +586,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         tables_commit();
         // an opaque copy of the thread index: the scatter / gather addresses below are loop invariant, and hoisted out of the
         // main loop they would cost the FAST path its registers for a once-per-frame use
-        u32 tid_o = (u32)tid;
+        u32 tid_o = (u32)gid;
         asm volatile("" : "+v"(tid_o));
         if (c_first == 0) {
             load_metrics();
@@ -709,7 +715,7 @@ template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) __attribute__((amdgpu_num_vgpr(60)))
 lds2_update_kernel_c120(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
 // the instantiation lds2_launch_update picks for (K, R): capped kernel or not, compile-time rate or not
-inline bool lds2_update_is_capped(int K) { return K == 11 || K == 14 || K == 15; }
+inline bool lds2_update_is_capped(int K) { return K == 10 || K == 11 || K == 14 || K == 15; }
 inline int lds2_update_rt(int K, int R) { return (K == 15 && R == 6) ? 6 : 0; }
 inline size_t lds2_smem_bytes(int K) {
     const size_t N = (size_t)1 << (K - 1), G = N / 16, GPT = G >= 256 ? 2 : 1;
@@ -736,7 +742,8 @@ inline bool lds2_kernel_resources(int K, int R, int shift, bool update, kd::Kern
 inline bool lds2_chainback_fits_beside_update(int K, int R, int shift) {
     kd::KernelResources u, c;
     if (!lds2_kernel_resources(K, R, shift, true, &u) || !lds2_kernel_resources(K, R, shift, false, &c)) return false;
-    const size_t threads = (((size_t)1 << (K - 1)) / 16) / ((((size_t)1 << (K - 1)) / 16) >= 256 ? 2 : 1);   // Lds2Geom<K>::T
+    size_t threads = (((size_t)1 << (K - 1)) / 16) / ((((size_t)1 << (K - 1)) / 16) >= 256 ? 2 : 1);   // Lds2Geom<K>::T
+    if (threads < 64) threads = 64;
     const size_t wg_per_cu = (160 * 1024) / lds2_smem_bytes(K);
     size_t waves_per_simd = (wg_per_cu * (threads / 64) + 3) / 4;          // what the LDS admits ...
     if (waves_per_simd > 512 / u.vgpr_alloc) waves_per_simd = 512 / u.vgpr_alloc;   // ... and what the register file does
@@ -838,7 +845,7 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-inline bool lds2_supported(int K, int R) { return K >= 11 && K <= 16 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
+inline bool lds2_supported(int K, int R) { return K >= 10 && K <= 16 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
 inline size_t lds2_threads(int K) { return ((size_t)1 << (K - 1)) / 16; }
 inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
     return ((frames + 1) / 2) * (L + (size_t)K - 1) * lds2_threads(K) * 4;
@@ -849,7 +856,7 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
     using GM = Lds2Geom<K>;
     void (*kern)(Lds2UpdateArgs) = nullptr;
     if constexpr (K == 15) kern = (a.R == 6) ? lds2_update_kernel_c120<K, SHIFT, 6> : lds2_update_kernel_c120<K, SHIFT, 0>;
-    else if constexpr (K == 11 || K == 14) kern = lds2_update_kernel_c120<K, SHIFT, 0>;
+    else if constexpr (K == 10 || K == 11 || K == 14) kern = lds2_update_kernel_c120<K, SHIFT, 0>;
     else kern = lds2_update_kernel<K, SHIFT, 0>;
     if (GM::smem_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -870,6 +877,7 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
 template <int SHIFT>
 int lds2_launch_update_k(int K, const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) {
     switch (K) {
+        case 10: return lds2_launch_update<10, SHIFT>(a, pairs, st);
         case 11: return lds2_launch_update<11, SHIFT>(a, pairs, st);
         case 12: return lds2_launch_update<12, SHIFT>(a, pairs, st);
         case 13: return lds2_launch_update<13, SHIFT>(a, pairs, st);

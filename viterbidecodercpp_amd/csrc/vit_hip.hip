@@ -408,7 +408,7 @@ static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
                         (g_last_error.empty() ? std::string("K must be 3..9 (R <= 4; K = 6: R = 2, 4; K = 8: R <= 2), linear branch table") : g_last_error));
     }
     if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
-        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 11..16 with R <= 6 and a linear branch table (see kernels_lds2.hpp)");
+        return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 10..16 with R <= 6 and a linear branch table (see kernels_lds2.hpp)");
     if (plan != VIT_HIP_PLAN_LDS && plan != VIT_HIP_PLAN_REG && plan != VIT_HIP_PLAN_LDS2)
         return fail(VIT_HIP_ERR_INVALID_ARG, "unknown plan");
     h->plan = plan;
