@@ -71,7 +71,7 @@ extern "C" {
 /* kernel plans (vit_hip_set_plan): which device implementation serves update()/chainback() */
 #define VIT_HIP_PLAN_AUTO 0
 #define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
-#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 3..9; R <= 4; K = 6: R = 2, 4; K = 8: R <= 2).
+#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 3..9; R <= 4, K = 7 and 9 also R = 5, 6; K = 6: R = 2, 4; K = 8: R <= 2).
                                The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32
@@ -109,6 +109,11 @@ int vit_hip_destroy(vit_hip_handle h);
 int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info);
 /* PLAN_AUTO never compiles anything: it resolves to a built-in plan (set VIT_HIP_JIT=1 before vit_hip_create to let it). */
 int vit_hip_set_plan(vit_hip_handle h, int plan);
+/* One line of text about the plan the handle runs and -- where that is PLAN_LDS, the compatibility plan -- whether a faster one
+ * exists for this (K, R) and how to get it: no combination the header-level is_valid admits lands on the slow plan silently.
+ * Thread-local storage, valid until the thread's next call.  (The reference has no counterpart: its strategies are chosen at
+ * compile time, include/viterbi/viterbi_decoder_scalar.h:25.) */
+const char* vit_hip_plan_note(vit_hip_handle h);
 
 /* Opaque blob carrying everything vit_hip_create needs (header + table + config): the payload broadcast to the other
  * ranks of a node (RCCL over xGMI via torch.distributed) so that every GPU builds an identical decoder. */

@@ -146,6 +146,8 @@ public:
     }
 
     vit_hip_handle hip_handle() const { return m_hip; }
+    // the kernel plan behind this decoder and, where it is the slow compatibility plan, how to get a faster one (vit_hip_plan_note)
+    const char* plan_note() const { return vit_hip_plan_note(m_hip); }
 
     // ---- deferred streaming (used by ViterbiDecoder_HIP::update) -------------------------------------------------------------
     // The reference's streaming callers hand update() the R symbols of ONE trellis step at a time

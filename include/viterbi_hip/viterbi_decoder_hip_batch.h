@@ -92,6 +92,8 @@ public:
         if (rank != root) table.refresh_levels();   // soft_decision_high()/low() must describe the rows that were received
     }
     vit_hip_handle hip_handle() const { return m_hip; }
+    // which plan serves this code and whether a faster one exists (vit_hip_plan_note): one line of text
+    const char* plan_note() const { return vit_hip_plan_note(m_hip); }
 
 private:
     static void check(int rc, const char* what) {

@@ -20,6 +20,8 @@ code = Code(f"K{K}", K, R, G)
 pc = get_decoding_config(dt, R)
 table = ViterbiBranchTable(K, R, G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
 dec = BatchDecoder(table, ViterbiDecoder_Config.from_decoder_config(pc))
+if dec.plan == _lib.PLAN_LDS and "PLAN_REG" in dec.plan_note.split(";", 1)[-1]:
+    dec.set_plan(_lib.PLAN_REG)          # the run-time compiled register plan (what vit_hip_plan_note points to)
 tx, sym = dec.synth(F, L, 3.0, seed=1)
 out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
 pipe = DecodePipeline(dec, F, L, options=_lib.VitHipPipelineOptions(**kw) if kw else None)
@@ -36,5 +38,5 @@ pipe.sync()
 dtm = (time.perf_counter() - t0) / steps * 1e3
 u, c, d = pipe.timing()
 ber = int(dec.count_bit_errors(out, tx).item()) / float(F * L)
-print(f"K{K} R{R} {dt} {F}x{L}: {dtm:.3f} ms per batch = {F * L / dtm / 1e6:.2f} Gbit/s; update {np.median(u):.3f} chainback {np.median(c):.3f} ms; "
+print(f"K{K} R{R} {dt} {F}x{L} [{_lib.PLAN_NAMES[dec.plan]}]: {dtm:.3f} ms per batch = {F * L / dtm / 1e6:.2f} Gbit/s; update {np.median(u):.3f} chainback {np.median(c):.3f} ms; "
       f"schedule ws={s.workspaces} upd={s.update_streams} overlapped={s.chainback_overlapped} sub={s.sub_batch_frames}; BER {ber:.2e}")

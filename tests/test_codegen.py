@@ -85,7 +85,7 @@ def test_k7_kernels_register_budget_and_counted_waits(tmp_path):
     # the update kernel's hot path falls through: the (rare) renormalisation bodies sit out of line behind not-taken
     # s_cbranch_vccnz, one per unrolled trellis step; a taken branch per step cost 1.4 - 1.9 % and made the speed depend on where
     # the linker put the kernel
-    for sym in (r"_ZN3vit17reg_update_kernelINS_7RegSpecILi7ELi2ELj109ELj79ELj0ELj0ELi2EEELi0EEEvNS_13RegUpdateArgsE",):
+    for sym in (r"_ZN3vit17reg_update_kernelINS_7RegSpecILi7ELi2ELj109ELj79ELj0ELj0ELi2ELj0ELj0EEELi0EEEvNS_13RegUpdateArgsE",):
         ulines, uloops = _inner_loops(_kernel_body(asm, sym))
         ua, ub = max(uloops, key=lambda ab: ab[1] - ab[0])
         labels = {m.group(1): n for n, l in enumerate(ulines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}

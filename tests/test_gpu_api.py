@@ -40,6 +40,52 @@ def test_plan_selection_and_errors():
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_AUTO) == _lib.OK
 
 
+@pytest.mark.parametrize("K,R,G,decode_type", [
+    (7, 6, (0o171, 0o133, 0o165, 0o117, 0o135, 0o157), "SOFT16"),
+    (7, 5, (0o171, 0o133, 0o165, 0o117, 0o135), "SOFT8"),
+    (9, 6, (0o557, 0o663, 0o711, 0o561, 0o753, 0o715), "SOFT16"),
+    (9, 5, (0o557, 0o663, 0o711, 0o561, 0o753), "HARD8"),
+])
+def test_rate_5_and_6_codes_on_the_register_plan(oracle, K, R, G, decode_type):
+    """R = 5, 6 at K = 7, 9: run-time compiled register-plan instantiations with SPLIT pattern tables (low / high part, two packed
+    instructions per butterfly to join them) -- not the compatibility plan.  Noisy frames long enough to renormalise, start / end
+    states, ragged lengths; PLAN_AUTO without VIT_HIP_JIT lands on PLAN_LDS and says what to do about it."""
+    code = Code(f"K{K}R{R}", K, R, tuple(G))
+    pc, table, config = make_table_config(code, decode_type)
+    auto = BatchDecoder(table, config)
+    assert auto.plan == _lib.PLAN_LDS and "vit_hip_set_plan(h, VIT_HIP_PLAN_REG)" in auto.plan_note and "COMPATIBILITY" in auto.plan_note
+    rng = np.random.default_rng(K * R)
+    for F, L in ((70, 1400), (33, 104), (3, 8)):
+        ss = rng.integers(0, code.num_states, F).astype(np.int32)
+        es = rng.integers(0, code.num_states, F).astype(np.int32)
+        dec = check_batch_against_oracle(oracle, code, decode_type, F, L, 2.0, seed=F + L, plan=_lib.PLAN_REG, start_state=ss, end_state=es)
+        assert dec.plan == _lib.PLAN_REG and dec.plan_note.startswith(f"K={K} R={R}: PLAN_REG")
+    # out-of-range symbols and a fuzzed configuration (the split sums wrap like the whole ones)
+    from tests.test_gpu_fuzz import random_config
+    from viterbidecodercpp_amd import ViterbiBranchTable, ViterbiDecoder_Config
+    width = 2 if decode_type == "SOFT16" else 1
+    for trial in range(3):
+        cfg = random_config(rng, width, trial)
+        sdt = np.int16 if width == 2 else np.int8
+        tb = ViterbiBranchTable(K, R, code.G, cfg.high, cfg.low, sdt)
+        cf = ViterbiDecoder_Config(cfg.max_error, cfg.initial_start_error, cfg.initial_non_start_error, cfg.renormalisation_threshold,
+                                   np.uint16 if width == 2 else np.uint8)
+        lim = 1 << (8 * width - 1)
+        F, L = 37, 150
+        sym = rng.integers(-lim, lim, size=(F, L + K - 1, R)).astype(sdt)
+        dec = BatchDecoder(tb, cf, plan=_lib.PLAN_REG)
+        import torch
+        met, rs = dec.update(torch.from_numpy(sym).cuda(), L)
+        got_dec = dec.export_decisions(F, L).cpu().numpy().view(np.uint64)
+        out = dec.chainback(F, L).cpu().numpy()
+        met = met.cpu().numpy()
+        met = met.view(np.uint16) if width == 2 else met
+        for f in range(F):
+            want = oracle.decode(K, R, code.G, cfg, sym[f], L)
+            assert np.array_equal(got_dec[f], want["decisions"]) and np.array_equal(out[f], want["bytes"]), (trial, f)
+            assert np.array_equal(met[f].astype(np.uint32), want["metrics"]) and int(rs[f].item()) == want["renorm_sum"], (trial, f)
+
+
 def test_custom_polynomials_decode(oracle):
     code = Code("NASA K=7 (171,133)", 7, 2, (0o171, 0o133))
     check_batch_against_oracle(oracle, code, "SOFT16", 5, 512, 2.0, seed=21)

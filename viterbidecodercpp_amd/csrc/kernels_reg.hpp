@@ -110,9 +110,17 @@ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 
 // ---- compile-time description of one code -------------------------------------------------------------------------
-template <int K_, int R_, u32 G0, u32 G1, u32 G2, u32 G3, int LANE_BITS_ = 2>
+template <int K_, int R_, u32 G0, u32 G1, u32 G2, u32 G3, int LANE_BITS_ = 2, u32 G4 = 0, u32 G5 = 0>
 struct RegSpec {
     static constexpr int K = K_, R = R_;
+    // R = 5, 6 (K = 7, 9): 2^R sums per step would be 4 - 8 KiB of LDS ring per step and wave.  The pattern is SPLIT instead: the
+    // low RL polynomials and the high R - RL each get their own table (8 + 4 or 8 + 8 entries: the ring of an R = 4 code), and
+    // the consumer forms E[p] = Elo[p_lo] + Ehi[p_hi], max_error - E[p] = (max_error - Elo[p_lo]) - Ehi[p_hi] with two packed
+    // instructions per butterfly.  Everything below that speaks of "a part" means the bit range [off, off + n) of the pattern.
+    static constexpr bool SPLIT = R_ > 4;
+    static constexpr int RL = SPLIT ? 3 : R_, RH = R_ - RL;      // polynomials of the low / high part
+    static constexpr int NPL = 1 << RL, NPH = SPLIT ? 1 << RH : 0;
+    static constexpr int NPROW = NPL + NPH;                      // table entries per step and frame pair
     static constexpr int SB = K - 1;              // state bits
     // LANE_BITS = 2: two state-slot bits live in the lane index (lane bits 4 and 5), 16 frame pairs per wave;
     // LANE_BITS = 0 (small K): every state of a frame pair lives in ONE lane's registers, 64 frame pairs per wave
@@ -124,7 +132,7 @@ struct RegSpec {
     static constexpr int DW = NREG >= 16 ? NREG / 16 : 1;  // decision dwords per lane per step
     static constexpr int SPS = 4 / DW;            // steps per 16-byte decision row
     static constexpr u32 SMASK = (1u << SB) - 1u;
-    static constexpr u32 G(int i) { return i == 0 ? G0 : i == 1 ? G1 : i == 2 ? G2 : G3; }
+    static constexpr u32 G(int i) { return i == 0 ? G0 : i == 1 ? G1 : i == 2 ? G2 : i == 3 ? G3 : i == 4 ? G4 : G5; }
 
     static constexpr u32 rotl(u32 x, int n) {
         n %= SB;
@@ -222,9 +230,11 @@ struct RegSpec {
     // per-lane base addresses for the whole kernel, and T p goes into the instruction's offset field.  The producer pays one
     // v_xor per pattern and group of four steps (the columns T e_j of its step are per-lane constants).
     static constexpr u32 lane_pat(int u, u32 q) { return LANE_BITS == 0 ? 0u : X3 ? pat_lane3(u % PER, q) : pat_lane(u % SB, q); }
+    // ... restricted to the n pattern bits from bit `off` (a part of a split pattern; the whole pattern: off = 0, n = R)
+    static constexpr u32 lane_pat_part(int u, u32 q, int off, int n) { return (lane_pat(u, q) >> off) & ((1u << n) - 1u); }
     // how the lane bits enter: 0: a, b independent (index ^ q); 1: a == b != 0 (^ q0^q1); 2: b == 0 (^ q0); 3: a == 0 (^ q1); 4: neither
-    static constexpr int bm_form(int u) {
-        const u32 a = lane_pat(u, 1), b = lane_pat(u, 2);
+    static constexpr int bm_form(int u, int off = 0, int n = R) {
+        const u32 a = lane_pat_part(u, 1, off, n), b = lane_pat_part(u, 2, off, n);
         return (a != 0 && b != 0 && a != b) ? 0 : (a != 0 && a == b) ? 1 : (a != 0) ? 2 : (b != 0) ? 3 : 4;
     }
     static constexpr int bm_form_bits(int f) { return f == 0 ? 2 : f == 4 ? 0 : 1; }      // low index bits the lane part touches
@@ -237,24 +247,24 @@ struct RegSpec {
         }
         return false;
     }
-    static constexpr BmBasis bm_basis(int u) {
+    static constexpr BmBasis bm_basis(int u, int off = 0, int nb = R) {
         BmBasis B{};
         int n = 0;
-        const u32 a = lane_pat(u, 1), b = lane_pat(u, 2);
-        const int f = bm_form(u);
+        const u32 a = lane_pat_part(u, 1, off, nb), b = lane_pat_part(u, 2, off, nb);
+        const int f = bm_form(u, off, nb);
         if (f == 0) { B.v[n++] = a; B.v[n++] = b; }
         else if (f == 1 || f == 2) B.v[n++] = a;
         else if (f == 3) B.v[n++] = b;
-        for (int j = 0; j < R && n < R; ++j)
+        for (int j = 0; j < nb && n < nb; ++j)
             if (!bm_in_span(B, n, 1u << j)) B.v[n++] = 1u << j;
         return B;
     }
-    // T p: the coordinates of pattern p in the basis of layout step u (bit k = coefficient of basis vector k)
-    static constexpr u32 bm_index(int u, u32 p) {
-        const BmBasis B = bm_basis(u);
-        for (u32 c = 0; c < (1u << R); ++c) {
+    // T p: the coordinates of (the part of) pattern p in the basis of layout step u (bit k = coefficient of basis vector k)
+    static constexpr u32 bm_index(int u, u32 p, int off = 0, int nb = R) {
+        const BmBasis B = bm_basis(u, off, nb);
+        for (u32 c = 0; c < (1u << nb); ++c) {
             u32 sum = 0;
-            for (int k = 0; k < R; ++k) if ((c >> k) & 1u) sum ^= B.v[k];
+            for (int k = 0; k < nb; ++k) if ((c >> k) & 1u) sum ^= B.v[k];
             if (sum == p) return c;
         }
         return 0;
@@ -288,16 +298,22 @@ struct RegChunk {
         return ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
     }
     static constexpr u32 pat(int PH, int h) { return SP::pat_reg(PH % SP::SB, (u32)r0(PH, h)); }
-    static constexpr int first(int PH, int h) {
+    // `part`: 0 the whole pattern, 1 / 2 the low / high part of a split pattern (RegSpec::SPLIT): a sub-chunk fetches every
+    // DISTINCT value of the part once
+    static constexpr u32 pat_part(int PH, int h, int part) {
+        const u32 p = pat(PH, h);
+        return part == 0 ? p : part == 1 ? (p & (u32)(SP::NPL - 1)) : (p >> SP::RL);
+    }
+    static constexpr int first(int PH, int h, int part = 0) {
         for (int k = h / CS * CS; k < h; ++k)
-            if (pat(PH, k) == pat(PH, h)) return k;
+            if (pat_part(PH, k, part) == pat_part(PH, h, part)) return k;
         return h;
     }
-    static constexpr int slot(int PH, int h) {
-        const int f = first(PH, h);
+    static constexpr int slot(int PH, int h, int part = 0) {
+        const int f = first(PH, h, part);
         int n = 0;
         for (int k = h / CS * CS; k < f; ++k)
-            if (first(PH, k) == k) ++n;
+            if (first(PH, k, part) == k) ++n;
         return n;
     }
 };
@@ -393,16 +409,20 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // a CU): the next group is produced INSIDE a group's last step, right behind the last fetch of the old one
     constexpr bool BMCHUNK = LDSBM && !SP::X3 && NREG >= 64 && NP >= 8;
     using RC = RegChunk<SP>;
-    constexpr int RING = !LDSBM ? 1 : BMCHUNK ? GROUP : (U0 * NP * 128 <= 16384 ? U0 : 8);
+    // R = 5, 6: the pattern is split into a low and a high part with a table each (RegSpec::SPLIT): NPROW entries per step
+    constexpr bool SPLIT = SP::SPLIT;
+    constexpr int RL = SP::RL, RH = SP::RH, NPL = SP::NPL, NPH = SP::NPH, NPROW = SP::NPROW;
+    static_assert(!SPLIT || LDSBM, "split patterns are an LDS-ring feature (K = 7, 9)");
+    constexpr int RING = !LDSBM ? 1 : BMCHUNK ? GROUP : (U0 * NPROW * 128 <= 16384 ? U0 : 8);
     // the 16-register codes (K = 7) unroll two periods (24 steps) so that the symbol ring below can run six groups ahead
     constexpr int U = LDSBM ? clcm(clcm(U0, RING), NREG == 16 ? 24 : 1) : clcm(clcm(SB, 16 / cgcd(16, BPS)), SPS);
     constexpr int NCH = LDSBM ? 0 : U * BPS / 16;
     // depth of the symbol register ring, in groups of 4 steps (a divisor of the block): 6 groups = 24 steps of load latency
     // hidden for K = 7 (+1 % alone and overlapped over 3 groups), 2 for K = 9 (a step is four times longer there)
     constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : (U / GROUP) % 2 == 0 ? 2 : (U / GROUP) % 7 == 0 ? 7 : 1);
-    constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4) or 3 (BPS <= 8)
-    static_assert(!LDSBM || (BPS <= 8 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
-    constexpr int ROW = NP * 16;                  // uint2 {E, EB} entries per step: [pattern][pair g]
+    constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4), 3 (BPS <= 8) or 4 (BPS <= 12)
+    static_assert(!LDSBM || (BPS <= 12 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
+    constexpr int ROW = NPROW * 16;               // uint2 {E, EB} entries per step: [pattern (SPLIT: low part, then high part)][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
@@ -490,8 +510,10 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             constexpr int c = decltype(cc)::value;
             static_for<R>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                constexpr u32 PACK = SP::bm_index((GROUP * c + 0) % PER, 1u << j) | (SP::bm_index((GROUP * c + 1) % PER, 1u << j) << 4) |
-                                     (SP::bm_index((GROUP * c + 2) % PER, 1u << j) << 8) | (SP::bm_index((GROUP * c + 3) % PER, 1u << j) << 12);
+                // (SPLIT: columns 0 .. RL-1 belong to the low part's basis, the others to the high part's)
+                constexpr int off = j < RL ? 0 : RL, nb = j < RL ? RL : RH;
+                constexpr u32 PACK = SP::bm_index((GROUP * c + 0) % PER, 1u << (j - off), off, nb) | (SP::bm_index((GROUP * c + 1) % PER, 1u << (j - off), off, nb) << 4) |
+                                     (SP::bm_index((GROUP * c + 2) % PER, 1u << (j - off), off, nb) << 8) | (SP::bm_index((GROUP * c + 3) % PER, 1u << (j - off), off, nb) << 12);
                 bm_col[c][j] = ((PACK >> (4u * q)) & 15u) << 7;
             });
         });
@@ -563,11 +585,16 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             const v2i32_t vb = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gvB + first_step * BPS), 0, 0);
             gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y;
             gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y;
-        } else {
+        } else if constexpr (NDW == 3) {
             const v3i32_t va = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gvA + first_step * BPS), 0, 0);
             const v3i32_t vb = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gvB + first_step * BPS), 0, 0);
             gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y; gA[sl][2] = (u32)va.z;
             gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y; gB[sl][2] = (u32)vb.z;
+        } else {
+            const v4i32_t va = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(gvA + first_step * BPS), 0, 0);
+            const v4i32_t vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(gvB + first_step * BPS), 0, 0);
+            gA[sl][0] = (u32)va.x; gA[sl][1] = (u32)va.y; gA[sl][2] = (u32)va.z; gA[sl][3] = (u32)va.w;
+            gB[sl][0] = (u32)vb.x; gB[sl][1] = (u32)vb.y; gB[sl][2] = (u32)vb.z; gB[sl][3] = (u32)vb.w;
         }
     };
 
@@ -581,7 +608,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // step `un` (un == U: step 0 of the NEXT block, whose chunks are already refilled).  Depends on symbols only, so it is
     // computed one step AHEAD, inside the basic block of the previous step's add-compare-select: its dependent chain
     // (perm -> sub -> neg -> max -> add -> sub) then overlaps ACS work instead of stalling the start of every step.
-    u32 E[2][BMCHUNK ? 1 : NP], EB[2][BMCHUNK ? 1 : NP];
+    u32 E[2][BMCHUNK || SPLIT ? 1 : NP], EB[2][BMCHUNK || SPLIT ? 1 : NP];
+    // SPLIT, whole-step look-ahead (K = 7): the two parts as they come out of the ring -- {Elo, max_error - Elo} and Ehi
+    u32 El[2][SPLIT && !BMCHUNK ? NPL : 1], EBl[2][SPLIT && !BMCHUNK ? NPL : 1], Eh[2][SPLIT && !BMCHUNK ? NPH : 1];
 #ifndef VIT_REG_CHUNK_AHEAD
 #define VIT_REG_CHUNK_AHEAD 1
 #endif
@@ -589,7 +618,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int NEB = 2 * AHEAD;               // ... and the buffers that takes (a power of two dividing the sub-chunks of a step)
     static_assert(RC::NSUB % NEB == 0 || !BMCHUNK, "buffer index = sub-chunk % NEB in every step");
     u32 Ec[NEB][RC::CS], EBc[NEB][RC::CS];       // BMCHUNK: [sub-chunk % NEB][slot]
+    u32 Hc[NEB][SPLIT ? RC::CS : 1];             // ... SPLIT: the high parts (Ec / EBc then hold the low parts)
     auto branch_metrics = [&](auto unc) __attribute__((always_inline)) {
+        if constexpr (!LDSBM) {
         constexpr int un = decltype(unc)::value;
         constexpr int us = un % U;            // position inside the (current or next) block
         constexpr int PHn = us % SB;
@@ -619,6 +650,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
             E[buf][p] = e;
             EB[buf][p] = pk_sub(MAXE2, e);
         });
+        }
     };
     static_assert(U % 2 == 0, "E double buffer alternates per step");
     // LDSBM producer: this lane's step of the group whose first step has ring slot `slot0`, from symbol ring slot `sl`
@@ -647,40 +679,69 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         // so that hipcc does not hoist the 2^R - 1 addresses of every group of the period out of the block loop, only the columns
         // stay resident and the xors run once per group
         constexpr int cls = (gs % (NCLS * GROUP)) / GROUP;
-        u32 waddr[NP];
-        waddr[0] = bm_wr;
-        if constexpr (BMCHUNK) asm volatile("" : "+v"(waddr[0]));    // (K = 7: registers to spare -- the addresses stay resident, no xor in the loop)
-        static_for<NP>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int p = decltype(pc)::value;
-            if constexpr (p != 0) {
-                constexpr int j = __builtin_ctz((unsigned)p);
-                waddr[p] = waddr[p & (p - 1)] ^ bm_col[cls][j];
-            }
-            u32 e = (p & 1) ? A1[0] : A0[0];
-            static_for<R - 1>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value + 1;
-                e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
+        // one part of the pattern (the whole of it unless SPLIT): polynomials off .. off + nb - 1, entries from `base` of the step's row
+        auto emit_part = [&](auto offc, auto nbc, auto basec) __attribute__((always_inline)) {
+            constexpr int off = decltype(offc)::value, nb = decltype(nbc)::value, base = decltype(basec)::value, NPP = 1 << nb;
+            u32 waddr[NPP];
+            waddr[0] = bm_wr;
+            if constexpr (BMCHUNK) asm volatile("" : "+v"(waddr[0]));    // (K = 7: registers to spare -- the addresses stay resident, no xor in the loop)
+            static_for<NPP>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p != 0) {
+                    constexpr int j = __builtin_ctz((unsigned)p);
+                    waddr[p] = waddr[p & (p - 1)] ^ bm_col[cls][off + j];
+                }
+                u32 e = (p & 1) ? A1[off] : A0[off];
+                static_for<nb - 1>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value + 1;
+                    e = pk_add(e, ((p >> i) & 1) ? A1[off + i] : A0[off + i]);
+                });
+                char* dst = (char*)bm_ring + waddr[p] + slot0 * ROW * 8 + base * 128;
+                if constexpr (base == 0) *(uint2*)dst = make_uint2(e, pk_sub(MAXE2, e));   // {E, max_error - E} (SPLIT: of the low part)
+                else *(u32*)dst = e;                                                       // the high part's sum alone
             });
-            *(uint2*)((char*)bm_ring + waddr[p] + slot0 * ROW * 8) = make_uint2(e, pk_sub(MAXE2, e));
-        });
+        };
+        emit_part(std::integral_constant<int, 0>{}, std::integral_constant<int, RL>{}, std::integral_constant<int, 0>{});
+        if constexpr (SPLIT) emit_part(std::integral_constant<int, RL>{}, std::integral_constant<int, RH>{}, std::integral_constant<int, NPL>{});
         // one wavefront per workgroup: LDS operations of a wave complete in order, so the other lanes' reads that follow
         // in program order see these rows; the fence only keeps the compiler from moving them across
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // where (part of) pattern `pv` of block step `us` sits in the ring for THIS lane: per-lane base of the step's lane form + the
+    // rest of the index as an instruction offset (part 0: the whole pattern, 1 / 2: low / high part of a split pattern)
+    auto bm_entry = [&](auto usc, auto pvc, auto partc) __attribute__((always_inline)) -> const char* {
+        constexpr int us = decltype(usc)::value, part = decltype(partc)::value, PHn = us % PER;
+        constexpr u32 pv = decltype(pvc)::value;
+        constexpr int off = part == 2 ? RL : 0, nb = part == 0 ? R : part == 1 ? RL : RH, base = part == 2 ? NPL : 0;
+        constexpr int f = SP::bm_form(PHn, off, nb), w = SP::bm_form_bits(f);
+        constexpr u32 tp = SP::bm_index(PHn, pv, off, nb);
+        return (const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + base * 128 + (us % RING) * ROW * 8;
+    };
     // LDSBM consumer: this lane's view of block step `un` (un == U: step 0 of the next block)
     auto bm_fetch = [&](auto unc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value;
-        constexpr int us = un % U, PHn = us % PER, buf = un & 1;
-        static_for<NP>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int p = decltype(pc)::value;
-            constexpr int f = SP::bm_form(PHn), w = SP::bm_form_bits(f);
-            constexpr u32 tp = SP::bm_index(PHn, (u32)p);
-            const uint2 v = *(const uint2*)((const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + (us % RING) * ROW * 8);
-            E[buf][p] = v.x;
-            EB[buf][p] = v.y;
-        });
+        constexpr int us = un % U, buf = un & 1;
+        if constexpr (!SPLIT) {
+            static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                const uint2 v = *(const uint2*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, (u32)p>{}, std::integral_constant<int, 0>{});
+                E[buf][p] = v.x;
+                EB[buf][p] = v.y;
+            });
+        } else {
+            static_for<NPL>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                const uint2 v = *(const uint2*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, (u32)p>{}, std::integral_constant<int, 1>{});
+                El[buf][p] = v.x;
+                EBl[buf][p] = v.y;
+            });
+            static_for<NPH>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                Eh[buf][p] = *(const u32*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, (u32)p>{}, std::integral_constant<int, 2>{});
+            });
+        }
     };
     // BMCHUNK consumer: the patterns sub-chunk `s` of block step `un` needs (un == U: step 0 of the next block)
     auto bm_fetch_chunk = [&](auto unc, auto sc) __attribute__((always_inline)) {
@@ -688,14 +749,26 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         constexpr int us = un % U, PHn = us % PER, buf = s % NEB;
         static_for<RC::CS>([&](auto kc) __attribute__((always_inline)) {
             constexpr int h = s * RC::CS + decltype(kc)::value;
-            if constexpr (RC::first(PHn, h) == h) {
-                constexpr u32 p = RC::pat(PHn, h);
-                constexpr int sl = RC::slot(PHn, h);
-                constexpr int f = SP::bm_form(PHn), w = SP::bm_form_bits(f);
-                constexpr u32 tp = SP::bm_index(PHn, p);
-                const uint2 v = *(const uint2*)((const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + (us % RING) * ROW * 8);
-                Ec[buf][sl] = v.x;
-                EBc[buf][sl] = v.y;
+            if constexpr (!SPLIT) {
+                if constexpr (RC::first(PHn, h) == h) {
+                    constexpr u32 p = RC::pat(PHn, h);
+                    constexpr int sl = RC::slot(PHn, h);
+                    const uint2 v = *(const uint2*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, p>{}, std::integral_constant<int, 0>{});
+                    Ec[buf][sl] = v.x;
+                    EBc[buf][sl] = v.y;
+                }
+            } else {
+                // every distinct low part and every distinct high part of the sub-chunk's patterns, once each
+                if constexpr (RC::first(PHn, h, 1) == h) {
+                    constexpr int sl = RC::slot(PHn, h, 1);
+                    const uint2 v = *(const uint2*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, RC::pat_part(PHn, h, 1)>{}, std::integral_constant<int, 1>{});
+                    Ec[buf][sl] = v.x;
+                    EBc[buf][sl] = v.y;
+                }
+                if constexpr (RC::first(PHn, h, 2) == h) {
+                    constexpr int sl = RC::slot(PHn, h, 2);
+                    Hc[buf][sl] = *(const u32*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, RC::pat_part(PHn, h, 2)>{}, std::integral_constant<int, 2>{});
+                }
             }
         });
     };
@@ -834,10 +907,20 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     u32 e_p, eb_p;
-                    if constexpr (BMCHUNK) {
+                    if constexpr (BMCHUNK && !SPLIT) {
                         static_assert(RC::r0(PH, h) == r0 && RC::pat(PH, h) == p, "RegChunk mirrors the butterfly enumeration");
                         e_p = Ec[(h / RC::CS) % NEB][RC::slot(PH, h)];
                         eb_p = EBc[(h / RC::CS) % NEB][RC::slot(PH, h)];
+                    } else if constexpr (BMCHUNK) {
+                        static_assert(RC::r0(PH, h) == r0 && RC::pat(PH, h) == p, "RegChunk mirrors the butterfly enumeration");
+                        // E[p] = Elo + Ehi, max_error - E[p] = (max_error - Elo) - Ehi: two packed instructions per butterfly
+                        const u32 eh = Hc[(h / RC::CS) % NEB][RC::slot(PH, h, 2)];
+                        e_p = pk_add(Ec[(h / RC::CS) % NEB][RC::slot(PH, h, 1)], eh);
+                        eb_p = pk_sub(EBc[(h / RC::CS) % NEB][RC::slot(PH, h, 1)], eh);
+                    } else if constexpr (SPLIT) {
+                        const u32 eh = Eh[cur][p >> RL];
+                        e_p = pk_add(El[cur][p & (NPL - 1)], eh);
+                        eb_p = pk_sub(EBl[cur][p & (NPL - 1)], eh);
                     } else {
                         e_p = E[cur][p];
                         eb_p = EB[cur][p];
@@ -1731,7 +1814,7 @@ struct RegCode {
     int id = -1;   // 0..6 in the order above; -1 with jit != nullptr for a run-time compiled code
     int K = 0, R = 0;
     int tile = 32; // frames per wavefront
-    uint32_t G[4] = {0, 0, 0, 0};
+    uint32_t G[6] = {0, 0, 0, 0, 0, 0};
     const RegJitModule* jit = nullptr;
 };
 
@@ -1751,6 +1834,7 @@ inline bool reg_code_init(RegCode* rc, int K, int R, const uint32_t* G, const De
         if (same) {
             rc->id = id; rc->K = K; rc->R = R; rc->tile = K < 7 ? 128 : 32;
             for (int i = 0; i < 4; ++i) rc->G[i] = table[id].G[i];
+            rc->G[4] = rc->G[5] = 0;
             return true;
         }
     }
@@ -1852,10 +1936,10 @@ inline bool reg_kernel_resources(const RegCode& rc, int shift, int kind, kd::Ker
         for (const auto& e : rc.jit->kernels)
             if (e.first == name) r = &e.second;
     } else {
-        // Itanium mangling of vit::<kernel><RegSpec<K, R, G0, G1, G2, G3, LANE_BITS>[, SHIFT]>(Args)
-        char spec[96], tail[48];
-        snprintf(spec, sizeof(spec), "7RegSpecILi%dELi%dELj%uELj%uELj%uELj%uELi%dEEE", rc.K, rc.R, rc.G[0], rc.G[1], rc.G[2], rc.G[3],
-                 reg_lane_bits(rc.K));
+        // Itanium mangling of vit::<kernel><RegSpec<K, R, G0, G1, G2, G3, LANE_BITS, G4, G5>[, SHIFT]>(Args)
+        char spec[128], tail[48];
+        snprintf(spec, sizeof(spec), "7RegSpecILi%dELi%dELj%uELj%uELj%uELj%uELi%dELj%uELj%uEEE", rc.K, rc.R, rc.G[0], rc.G[1], rc.G[2], rc.G[3],
+                 reg_lane_bits(rc.K), rc.G[4], rc.G[5]);
         snprintf(tail, sizeof(tail), "ELi%dEEEvNS_13RegUpdateArgsE", shift ? 8 : 0);
         std::vector<std::string> frag;
         if (kind == REG_KERNEL_UPDATE) frag = {"17reg_update_kernelI", spec, tail};

@@ -39,6 +39,7 @@ namespace vit {
 inline bool reg_jit_supported(int K, int R) {
     if (K == 6) return R == 2 || R == 4;
     if (K == 8) return R == 1 || R == 2;      // the 28-step block of 7 state bits only keeps its LDS ring whole for <= 4 patterns
+    if ((K == 7 || K == 9) && (R == 5 || R == 6)) return true;   // split pattern tables (RegSpec::SPLIT)
     return (K == 3 || K == 4 || K == 5 || K == 7 || K == 9) && R >= 1 && R <= 4;
 }
 
@@ -136,7 +137,7 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 // returns nullptr and fills `err` on failure.  The module belongs to the current device.
 inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int device, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5,7,9} with R <= 4, K = 6 with R = 2 or 4, K = 8 with R <= 2"; return nullptr; }
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5} with R <= 4, K in {7,9} with R <= 6, K = 6 with R = 2 or 4, K = 8 with R <= 2"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");
@@ -160,7 +161,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
     h = fnv1a_str(arch, h);
     std::ostringstream key;
     key << "reg_K" << K << "R" << R;
-    for (int i = 0; i < 4; ++i) key << "_" << (i < R ? G[i] : 0u);
+    for (int i = 0; i < 6; ++i) key << "_" << (i < R ? G[i] : 0u);
     key << "_" << arch << "_" << std::hex << h;
     const std::string mkey = key.str() + "@" + std::to_string(device);
     auto it = modules().find(mkey);
@@ -180,7 +181,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
             f << "#include \"" << src_dir << "/kernels_reg.hpp\"\n"
               << "using SP = vit::RegSpec<" << K << ", " << R;
             for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
-            f << ", " << lane_bits << ">;\n"
+            f << ", " << lane_bits << ", " << (4 < R ? G[4] : 0u) << "u, " << (5 < R ? G[5] : 0u) << "u>;\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, false>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, false>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"

@@ -385,6 +385,30 @@ int vit_hip_destroy(vit_hip_handle h) {
     return VIT_HIP_OK;
 }
 
+const char* vit_hip_plan_note(vit_hip_handle h) {
+    if (!h) return "NULL handle";
+    thread_local std::string note;
+    char head[160];
+    snprintf(head, sizeof(head), "K=%d R=%d: %s", h->K, h->R,
+             h->plan == VIT_HIP_PLAN_REG ? "PLAN_REG (state metrics in registers, 32-128 frames per wavefront)"
+             : h->plan == VIT_HIP_PLAN_LDS2 ? "PLAN_LDS2 (frame pair per workgroup, four trellis steps per barrier)"
+                                            : "PLAN_LDS, the COMPATIBILITY plan (one frame per workgroup: ~20x slower per state update than the other plans)");
+    note = head;
+    if (h->plan == VIT_HIP_PLAN_LDS) {
+        if (h->reg_ok || (h->linear && vit::reg_jit_supported(h->K, h->R)))
+            note += h->reg_ok ? "; the register plan is available: vit_hip_set_plan(h, VIT_HIP_PLAN_REG)"
+                              : "; a register-plan instantiation for these polynomials can be compiled at run time: vit_hip_set_plan(h, VIT_HIP_PLAN_REG) "
+                                "(hipcc, 30-60 s once, cached on disk), or VIT_HIP_JIT=1 before vit_hip_create";
+        else if (h->lds2_ok)
+            note += "; PLAN_LDS2 is available: vit_hip_set_plan(h, VIT_HIP_PLAN_LDS2)";
+        else if (!h->linear)
+            note += "; no faster plan: the branch table is not that of a linear convolutional code";
+        else
+            note += "; no faster plan exists for this (K, R): the register plan serves K = 3..9 (R <= 4; K = 7, 9: R <= 6; K = 6: R = 2, 4; K = 8: R <= 2), PLAN_LDS2 K = 10..16 with R <= 6";
+    }
+    return note.c_str();
+}
+
 int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
     if (!h || !info) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL argument");
     memset(info, 0, sizeof(*info));
@@ -405,7 +429,7 @@ static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
         g_last_error.clear();
         if (!guard.ok || !try_reg_jit(h))
             return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG not available for this code: " +
-                        (g_last_error.empty() ? std::string("K must be 3..9 (R <= 4; K = 6: R = 2, 4; K = 8: R <= 2), linear branch table") : g_last_error));
+                        (g_last_error.empty() ? std::string("K must be 3..9 (R <= 4, K = 7 and 9 also R = 5, 6; K = 6: R = 2, 4; K = 8: R <= 2), linear branch table") : g_last_error));
     }
     if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
         return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 10..16 with R <= 6 and a linear branch table (see kernels_lds2.hpp)");

@@ -284,6 +284,11 @@ class BatchDecoder:
         _lib.check(_lib.load().vit_hip_set_plan(self._handle._h, plan))
         self._handle.refresh()
 
+    @property
+    def plan_note(self) -> str:
+        """vit_hip_plan_note: which plan runs and, where that is the slow compatibility plan, whether a faster one exists"""
+        return _lib.load().vit_hip_plan_note(self._handle._h).decode()
+
     def workspace_bytes(self, frames: int, L: int) -> int:
         return _lib.load().vit_hip_workspace_bytes(self._handle._h, frames, L)
 
