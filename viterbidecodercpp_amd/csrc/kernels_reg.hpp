@@ -120,7 +120,10 @@ struct RegSpec {
     static constexpr bool SPLIT = R_ > 4;
     static constexpr int RL = SPLIT ? 3 : R_, RH = R_ - RL;      // polynomials of the low / high part
     static constexpr int NPL = 1 << RL, NPH = SPLIT ? 1 << RH : 0;
-    static constexpr int NPROW = NPL + NPH;                      // table entries per step and frame pair
+    // table entries per step and frame pair: a power of two (R = 5: 8 + 4 padded to 16), because the producer forms its write
+    // addresses by XOR on top of the row's base (q x row bytes must not share bits with the index)
+    static constexpr int NPROW = (NPL + NPH) <= 8 ? (NPL + NPH <= 4 ? (NPL + NPH <= 2 ? NPL + NPH : 4) : 8) : 16;
+    static_assert(!SPLIT || NPL + NPH <= 16, "split tables: at most 8 + 8 entries");
     static constexpr int SB = K - 1;              // state bits
     // LANE_BITS = 2: two state-slot bits live in the lane index (lane bits 4 and 5), 16 frame pairs per wave;
     // LANE_BITS = 0 (small K): every state of a frame pair lives in ONE lane's registers, 64 frame pairs per wave
@@ -420,7 +423,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // depth of the symbol register ring, in groups of 4 steps (a divisor of the block): 6 groups = 24 steps of load latency
     // hidden for K = 7 (+1 % alone and overlapped over 3 groups), 2 for K = 9 (a step is four times longer there)
     constexpr int NG = !LDSBM ? 1 : ((U / GROUP) % 6 == 0 ? 6 : (U / GROUP) % 3 == 0 ? 3 : (U / GROUP) % 2 == 0 ? 2 : (U / GROUP) % 7 == 0 ? 7 : 1);
-    constexpr int NDW = (BPS + 6) / 4;            // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4), 3 (BPS <= 8) or 4 (BPS <= 12)
+    constexpr int NDW = (BPS + 3) / 4 + 1;        // dwords that cover BPS bytes at any byte phase: 2 (BPS <= 4), 3 (BPS <= 8) or 4 (BPS <= 12)
     static_assert(!LDSBM || (BPS <= 12 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
     constexpr int ROW = NPROW * 16;               // uint2 {E, EB} entries per step: [pattern (SPLIT: low part, then high part)][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
