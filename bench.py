@@ -76,10 +76,13 @@ def parse():
                          "update of step i+1; 1: both kernels back to back on one stream; 0 (default): the rule of "
                          "vit_hip_pipeline_submit -- 2 for the register plan with at most two update waves per SIMD (the "
                          "headline configuration), else 1")
-    ap.add_argument("--via", default="pipeline", choices=["pipeline", "python"],
+    ap.add_argument("--via", default=None, choices=["pipeline", "python", "host"],
                     help="pipeline (default): the timed loop calls the shipped C API only -- vit_hip_pipeline_submit per step, "
                          "vit_hip_pipeline_sync at the end; the library picks the schedule (--pipeline is ignored).  python: the "
-                         "same schedule rebuilt from torch streams around vit_hip_update_batch / vit_hip_chainback_batch (A/B)")
+                         "same schedule rebuilt from torch streams around vit_hip_update_batch / vit_hip_chainback_batch (A/B).  host "
+                         "(the default of --config 0): ONE decoder object with host-resident state, the header-level drop-in's call "
+                         "pattern reset -> update -> chainback per step (vit_hip_update_host / vit_hip_chainback_host: the single-frame "
+                         "latency route)")
     ap.add_argument("--config", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="BASELINE.json configs[i]: 0 = K7 soft16 1 frame x 4096; 1 = K7 soft16 65536 x 8192 (the default "
                          "workload); 2 = K9 soft16 65536 x 8192; 3 = K7 hard8, 262144 frames over 8 GPUs = 32768 per GPU "
@@ -95,6 +98,8 @@ def parse():
     if args.config is not None:
         code, dt, frames, bits, ebn0 = BASELINE_CONFIGS[args.config]
         args.code, args.decode_type, args.frames, args.bits, args.ebn0 = code, dt, frames, bits, ebn0
+    if args.via is None:
+        args.via = "host" if args.config == 0 else "pipeline"
     return args
 
 
@@ -360,12 +365,103 @@ def dry_run(args, world, rank, affinity):
                       "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world, "per_rank": per_rank_info}}))
 
 
+def host_route(args):
+    """BASELINE configs[0]: one frame through the drop-in's own call pattern (examples/run_simple.cpp:67-80) -- a single decoder
+    object whose state lives on the host, update() and chainback() each one GPU launch (csrc/kernels_one.hpp for K <= 7).  A step =
+    reset -> update(whole frame) -> chainback; the host-pointer boundary is part of the route (PCIe copies of 16 - 64 KiB each way
+    are inside the timed region: they ARE the product here), so this line is a latency figure, not the throughput headline."""
+    import numpy as np
+    from oracle import pyoracle
+    from viterbidecodercpp_amd import (COMMON_CODES, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core, ViterbiDecoder_HIP,
+                                       get_decoding_config, synth)
+
+    code = COMMON_CODES[args.code]
+    pc = get_decoding_config(args.decode_type, code.R)
+    L = args.bits
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    vitdec = ViterbiDecoder_Core(table, ViterbiDecoder_Config.from_decoder_config(pc))
+    tx, sym = synth.make_frames_numpy(code, pc, 1, L, args.ebn0, seed=1)
+    flat = sym[0].reshape(-1)
+    vitdec.set_traceback_length(L)
+    t_upd, t_cb = [], []
+
+    def one():
+        vitdec.reset()
+        t0 = time.perf_counter()
+        acc = ViterbiDecoder_HIP.update(vitdec, flat)
+        t1 = time.perf_counter()
+        out = vitdec.chainback(L)
+        t2 = time.perf_counter()
+        t_upd.append(t1 - t0)
+        t_cb.append(t2 - t1)
+        return acc, out
+
+    for _ in range(args.warmup):
+        one()
+    del t_upd[:], t_cb[:]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc, out = one()
+    elapsed = time.perf_counter() - t0
+    S = L + code.K - 1
+    dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[args.decode_type]
+    ocfg = pyoracle.stock_config(dt, code.R)
+    pyoracle.ensure_built()
+    ref = pyoracle.RefLib() if pyoracle.RefLib.available() else None
+    want = ref.run(args.code, ocfg, sym[0], L, simd=pyoracle.SCALAR) if ref else pyoracle.Oracle().decode(code.K, code.R, code.G, ocfg, sym[0], L)
+    ok_b = bool(np.array_equal(out, want["bytes"]))
+    ok_d = bool(np.array_equal(np.asarray(vitdec.m_decisions).reshape(S, -1), np.asarray(want["decisions"])[:S].reshape(S, -1)))
+    step_ms = elapsed / args.steps * 1e3
+    sb = pc.soft_bytes
+    frame_bytes = S * code.R * sb + S * 8 + L * 8 + L // 8          # SURVEY 8(d): symbols in, decision rows out, one word per step back, bytes out
+    result = {
+        "metric": "decoded Mbit/s (= ACS trellis steps/s), update()+chainback(), bit-exact vs scalar reference",
+        "value": L * args.steps / elapsed / 1e6, "unit": "Mbit/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
+        "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type}, ONE frame of {L} info bits through the header-level drop-in "
+                               f"(ViterbiDecoder_HIP::update + ViterbiDecoder_Core::chainback, host-resident state), AWGN Eb/N0={args.ebn0} dB",
+                   "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": "one wavefront, lane == state (csrc/kernels_one.hpp)" if code.K <= 7 else "lds"},
+        "update_ms": float(np.median(t_upd)) * 1e3, "chainback_ms": float(np.median(t_cb)) * 1e3,
+        "ms_per_step_median": float(np.median(np.asarray(t_upd) + np.asarray(t_cb))) * 1e3,
+        "ns_per_trellis_step_update": float(np.median(t_upd)) / S * 1e9,
+        # a dependent chain of S steps on one wavefront: the HBM roofline does not bound it; quoted for the record's shape only
+        "roofline": {"bound": "hbm", "kernel": "single-frame update (latency route)", "achieved": frame_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": frame_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "note": "latency-bound: one frame is a chain of L + K - 1 dependent steps on ONE wavefront; the figure of merit is ns per step"},
+        "parity": {"frames_checked_vs_scalar_reference": 1, "checker": "reference (oracle/_ref)" if ref else "port (oracle/)",
+                   "chainback_bytes_bit_exact": ok_b, "decision_words_bit_exact": ok_d, "bit_exact": ok_b and ok_d},
+        "ber": float(np.unpackbits(out ^ tx[0]).mean()),
+    }
+    if ref and not args.no_cpu_baseline:
+        topo = host_cpu_topology()
+        res = {}
+        for name, simd in (("scalar", pyoracle.SCALAR), ("avx", pyoracle.SIMD_AVX)):
+            if simd != pyoracle.SCALAR and not ref.is_valid(args.code, pc.soft_bytes, simd):
+                continue
+            s1, _ = ref.bench(args.code, ocfg, sym, 1, L, simd=simd, threads=1, passes=1, sweeps=1, cpus=topo["cpus"][:1])
+            sweeps = max(1, int(0.2 / max(s1[0], 1e-6)))
+            s1, _ = ref.bench(args.code, ocfg, sym, 1, L, simd=simd, threads=1, passes=5, sweeps=sweeps, cpus=topo["cpus"][:1])
+            res[name] = L * sweeps / float(np.median(s1)) / 1e6
+        result["cpu_baseline"] = {"value": res.get("scalar"), "unit": "Mbit/s", "cores": 1, "kind": "reference", "strategy": "ViterbiDecoder_Scalar",
+                                  "sample": f"the same frame, reset -> update -> chainback on ONE core, median of 5 passes of >= 0.2 s",
+                                  "simd_1thread_Mbit_s": res.get("avx"), "ms_per_frame_scalar": L / res["scalar"] / 1e3 if res.get("scalar") else None,
+                                  "ms_per_frame_avx": L / res["avx"] / 1e3 if res.get("avx") else None, "host": {k: v for k, v in topo.items() if k != "cpus"}}
+        result["speedup_vs_cpu_baseline"] = result["value"] / res["scalar"] if res.get("scalar") else None
+    print(json.dumps(result))
+
+
 def main():
     args = parse()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)          # never returns
+    if args.via == "host":
+        if args.gpus != 1 or args.frames != 1:
+            sys.exit("bench.py --via host is the single-frame, single-GPU latency route (--config 0)")
+        import torch  # noqa: F401  (one HIP runtime per process: torch's)
+        return host_route(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world} from the launcher")

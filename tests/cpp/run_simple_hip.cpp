@@ -4,6 +4,8 @@
 #include <inttypes.h>
 #include <stdio.h>
 
+#include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "viterbi_hip/viterbi_decoder_core.h"
@@ -31,6 +33,22 @@ int main() {
     const uint64_t error = accumulated_error + uint64_t(vitdec.get_error());
     vitdec.chainback(rx.data(), total_input_bits);
     printf("error_metric=%" PRIu64 "\n", error);
+
+    // the latency of the route: reset -> update -> chainback of the same 8192-bit frame, median of 21 (BASELINE configs[0]'s call
+    // pattern; the single-frame kernels of csrc/kernels_one.hpp serve every K <= 7)
+    {
+        std::vector<double> us;
+        for (int rep = 0; rep < 21; rep++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            vitdec.reset();
+            (void)Decoder::template update<uint64_t>(vitdec, symbols.data(), symbols.size());
+            vitdec.chainback(rx.data(), total_input_bits);
+            us.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6);
+        }
+        std::sort(us.begin(), us.end());
+        printf("latency: update + chainback of one %zu-bit frame: median %.1f us, min %.1f us (%.1f Mbit/s)\n", total_input_bits, us[10], us[0],
+               double(total_input_bits) / us[10]);
+    }
 
     const size_t total_errors = count_bit_errors(tx, rx);
     printf("%zu/%zu incorrect bits\n", total_errors, total_input_bits);

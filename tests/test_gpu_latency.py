@@ -1,0 +1,113 @@
+"""The single-frame latency route (csrc/kernels_one.hpp) behind vit_hip_update_host / vit_hip_chainback_host, i.e. behind the
+header-level drop-in ViterbiDecoder_HIP.update() + ViterbiDecoder_Core.chainback() of ONE decoder object (the reference's
+examples/run_simple.cpp:67-80; BASELINE configs[0]): one wavefront, lane == state, for every K <= 7.  Everything the reference
+leaves behind is compared with the oracle: decision rows, metrics, the renormalisation sum per call, chainback bytes."""
+import time
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_table_config, oracle_cfg
+from viterbidecodercpp_amd import (COMMON_CODES, Code, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core, ViterbiDecoder_HIP,
+                                   synth)
+
+pytestmark = pytest.mark.gpu
+
+CODES = [COMMON_CODES[0], COMMON_CODES[1], COMMON_CODES[2], COMMON_CODES[3], COMMON_CODES[4],
+         Code("K2", 2, 2, (0b11, 0b11)), Code("K4 R3", 4, 3, (0o15, 0o17, 0o13)), Code("K6 R1", 6, 1, (0o65,)),
+         Code("K7 R6", 7, 6, (0o171, 0o133, 0o165, 0o117, 0o135, 0o157)), Code("K7 R8", 7, 8, (0o171, 0o133, 0o165, 0o117, 0o135, 0o157, 0o145, 0o173))]
+
+
+@pytest.mark.parametrize("decode_type", ["SOFT16", "SOFT8", "HARD8"])
+@pytest.mark.parametrize("code", CODES, ids=lambda c: c.name.replace(" ", "_"))
+def test_single_frame_route_matches_the_oracle(oracle, code, decode_type):
+    """whole-frame update, then the same frame in ragged pieces (1, 63, 64, 65, 200 ... steps: the kernel works in groups of 64
+    steps), start and end states, a trace length that is no multiple of 8, frames longer than the chainback's 8192-step LDS chunk"""
+    pc, table, config = make_table_config(code, decode_type)
+    cfg = oracle_cfg(decode_type, code.R)
+    rng = np.random.default_rng(code.K * 10 + code.R)
+    for L, pieces in ((1300, None), (777, (1, 63, 64, 65, 200, 7, 128)), (20011, (5000, 9000)), (5, None)):
+        # (the generator wants whole bytes: the symbol stream of a frame of ceil8(L) bits, cut after L + K-1 steps)
+        S = L + code.K - 1
+        _, sym = synth.make_frames_numpy(code, pc, 1, (L + 7) // 8 * 8, 2.0, seed=L)
+        sym = np.ascontiguousarray(sym[:, :S])
+        flat = sym[0].reshape(-1)
+        ss, es = int(rng.integers(0, code.num_states)), int(rng.integers(0, code.num_states))
+        want = oracle.decode(code.K, code.R, code.G, cfg, sym[0], L, start_state=ss, end_state=es)
+        vitdec = ViterbiDecoder_Core(table, config)
+        vitdec.set_traceback_length(L)
+        vitdec.reset(ss)
+        acc, t = 0, 0
+        if pieces is None:
+            acc += ViterbiDecoder_HIP.update(vitdec, flat)
+        else:
+            k = 0
+            while t < S:
+                n = min(pieces[k % len(pieces)], S - t)
+                acc += ViterbiDecoder_HIP.update(vitdec, flat[t * code.R:(t + n) * code.R])
+                t += n
+                k += 1
+        acc += vitdec.take_unreported_renormalisation()
+        assert vitdec.get_error(es) == want["error"], (L, pieces)
+        acc += vitdec.take_unreported_renormalisation()
+        assert acc == want["renorm_sum"], (L, pieces)
+        assert np.array_equal(vitdec.m_metrics.astype(np.uint32), want["metrics"])
+        assert np.array_equal(np.asarray(vitdec.m_decisions).reshape(S, -1), want["decisions"].reshape(S, -1)), (L, pieces)
+        assert np.array_equal(vitdec.chainback(L, es), want["bytes"]), (L, pieces)
+
+
+def test_single_frame_latency_of_the_drop_in_route(oracle):
+    """BASELINE configs[0]'s call pattern on one 8192-bit Voyager frame: reset -> update -> chainback through the header-level
+    drop-in must stay under a millisecond end to end (round 4: 3.3 ms through the general LDS kernel; the reference's scalar
+    decoder needs 0.68 ms for the same frame on one core of the box, its AVX2 strategy 0.05 ms)."""
+    code = COMMON_CODES[2]
+    pc, table, config = make_table_config(code, "SOFT16")
+    L = 8192
+    tx, sym = synth.make_frames_numpy(code, pc, 1, L, 3.0, seed=3)
+    flat = sym[0].reshape(-1)
+    vitdec = ViterbiDecoder_Core(table, config)
+    vitdec.set_traceback_length(L)
+    times = []
+    for rep in range(8):
+        vitdec.reset()
+        t0 = time.perf_counter()
+        ViterbiDecoder_HIP.update(vitdec, flat)
+        out = vitdec.chainback(L)
+        times.append(time.perf_counter() - t0)
+    assert np.array_equal(out, tx[0])
+    best = sorted(times[2:])[len(times[2:]) // 2]
+    print(f"single 8192-bit K7 frame, update + chainback through the drop-in: median {best * 1e3:.3f} ms")
+    assert best < 1.5e-3, times
+
+
+@pytest.mark.parametrize("K", [7, 5, 3, 2])
+def test_parallel_chainback_is_exact_when_its_guesses_are_wrong(oracle, K):
+    """The single-frame chainback chases 64 segments of the frame at once from GUESSED top states and repairs the wrong guesses.
+    Real decision rows make every guess right (survivor paths merge within a few constraint lengths); rows of random bits keep
+    paths apart, so here the repair pass does the work -- and rows that decide 'predecessor 0' everywhere or repeat with a short
+    period stress the boundaries.  Lengths: ragged top byte, several 8192-step chunks, frames shorter than 64 segments."""
+    import ctypes as C
+    from viterbidecodercpp_amd import _lib
+
+    code = Code(f"K{K}", K, 2, ((1 << K) - 1, (1 << (K - 1)) | 1))
+    pc, table, config = make_table_config(code, "SOFT16")
+    vitdec = ViterbiDecoder_Core(table, config)           # only its handle is used: the rows below are not a decoder's
+    lib = _lib.load()
+    rng = np.random.default_rng(K)
+    N = code.num_states
+    for L in (8192, 8191, 20000, 16389, 517, 64, 9, 1):
+        S = L + K - 1
+        for kind in ("random", "zeros", "period3"):
+            if kind == "random":
+                rows = rng.integers(0, 1 << 63, size=S, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=S).astype(np.uint64)
+            elif kind == "zeros":
+                rows = np.zeros(S, dtype=np.uint64)
+            else:
+                rows = np.tile(rng.integers(0, 1 << 62, size=3, dtype=np.uint64), S // 3 + 1)[:S].copy()
+            if N < 64:
+                rows &= np.uint64((1 << N) - 1)
+            for es in (0, N - 1, int(rng.integers(0, N))):
+                want = oracle.chainback(K, rows.reshape(S, 1), L, es)
+                out = np.zeros((L + 7) // 8, dtype=np.uint8)
+                assert lib.vit_hip_chainback_host(vitdec._handle._h, rows.ctypes.data_as(C.c_void_p), L, es, out.ctypes.data_as(C.c_void_p)) == _lib.OK
+                assert np.array_equal(out, want), (L, kind, es)

@@ -20,6 +20,7 @@
 #include "../../include/vit_hip_experiments.h"
 #include "kernels_lds.hpp"
 #include "kernels_lds2.hpp"
+#include "kernels_one.hpp"
 #include "kernels_reg.hpp"
 #include "kernels_synth.hpp"
 #include "reg_jit.hpp"
@@ -1273,9 +1274,25 @@ int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbo
     memcpy(hs, metrics_inout, met_bytes);
     memcpy(hs + met_b + rs_b, symbols, sym_bytes);
     VIT_HIP_CHECK(hipMemcpyAsync(base, hs, met_b + rs_b + sym_bytes, hipMemcpyHostToDevice, h->stream));
-    // streaming state lives on the host between calls, so this route always runs the LDS plan on one frame
-    rc = lds_update(h, d_sym, n_steps * (size_t)h->R, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
-    if (rc != VIT_HIP_OK) return rc;
+    // streaming state lives on the host between calls: one frame.  K <= 7 (at most 64 states): the one-wavefront latency kernel
+    // (kernels_one.hpp: lane == state, metrics in a register, ~100 clocks per step); larger codes: the LDS plan on one frame
+    if (vit::one_supported(h->K, h->R)) {
+        vit::OneUpdateArgs oa{};
+        oa.symbols = d_sym;
+        oa.sym_total_bytes = sym_bytes;
+        oa.decisions = d_dec;
+        oa.metrics_io = d_met;
+        oa.renorm_sum = d_rs;
+        oa.pattern = h->d_pattern;
+        oa.K = h->K;
+        oa.n_steps = (int)n_steps;
+        oa.cfg = h->cfg;
+        if ((h->shift ? vit::one_launch_update<8>(h->R, oa, h->stream) : vit::one_launch_update<0>(h->R, oa, h->stream)) != 0)
+            return fail(VIT_HIP_ERR_RUNTIME, "single-frame update launch failed");
+    } else {
+        rc = lds_update(h, d_sym, n_steps * (size_t)h->R, 1, n_steps, n_steps, 0, d_dec, d_met, false, d_rs, nullptr, h->stream);
+        if (rc != VIT_HIP_OK) return rc;
+    }
     // out: metrics and renorm sum sit in front of the symbols, the decision rows behind them: copy [metrics | rs] and the rows
     // as one contiguous range when the symbols are short (the common streaming case), else as two
     if (sym_b <= 4096) {
@@ -1310,12 +1327,35 @@ int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L
     uint8_t* base = (uint8_t*)h->d_scratch;
     uint32_t es = (uint32_t)end_state;
     uint32_t* d_es = (uint32_t*)(base + dec_b + out_b);
-    VIT_HIP_CHECK(hipMemcpyAsync(base, decisions, rows * (size_t)h->W * 8, hipMemcpyHostToDevice, h->stream));
-    VIT_HIP_CHECK(hipMemcpyAsync(d_es, &es, 4, hipMemcpyHostToDevice, h->stream));
-    rc = lds_chainback(h, (const uint64_t*)base, 1, L, base + dec_b, d_es, h->stream);
+    // one pinned staging copy each way (pageable copies go through the runtime's own staging and synchronise more often)
+    const size_t dec_bytes = rows * (size_t)h->W * 8, out_bytes = (L + 7) / 8;
+    rc = ensure_stage(h, dec_b + out_b);
     if (rc != VIT_HIP_OK) return rc;
-    VIT_HIP_CHECK(hipMemcpyAsync(bytes_out, base + dec_b, (L + 7) / 8, hipMemcpyDeviceToHost, h->stream));
+    uint8_t* hs = (uint8_t*)h->h_stage;
+    memcpy(hs, decisions, dec_bytes);
+    VIT_HIP_CHECK(hipMemcpyAsync(base, hs, dec_bytes, hipMemcpyHostToDevice, h->stream));
+    if (vit::one_supported(h->K, h->R)) {
+        // K <= 7: rows staged through LDS by the whole wavefront, one lane chases (kernels_one.hpp); the end state is a kernel argument
+        vit::OneChainbackArgs ca{};
+        ca.decisions = (const uint64_t*)base;
+        ca.out = base + dec_b;
+        ca.end_state = es;
+        ca.L = (uint32_t)L;
+        ca.K = h->K;
+        if (L > 0xFFFFFFF0ull) return fail(VIT_HIP_ERR_INVALID_ARG, "L too large");
+        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vit::one_chainback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)vit::one_chainback_lds_bytes()) == hipSuccess;
+        if (!attr_ok) return fail(VIT_HIP_ERR_RUNTIME, "hipFuncSetAttribute(one_chainback_kernel) failed");
+        hipLaunchKernelGGL(vit::one_chainback_kernel, dim3(1), dim3(64), vit::one_chainback_lds_bytes(), h->stream, ca);
+        VIT_HIP_CHECK(hipGetLastError());
+    } else {
+        VIT_HIP_CHECK(hipMemcpyAsync(d_es, &es, 4, hipMemcpyHostToDevice, h->stream));
+        rc = lds_chainback(h, (const uint64_t*)base, 1, L, base + dec_b, d_es, h->stream);
+        if (rc != VIT_HIP_OK) return rc;
+    }
+    VIT_HIP_CHECK(hipMemcpyAsync(hs + dec_b, base + dec_b, out_bytes, hipMemcpyDeviceToHost, h->stream));
     VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(bytes_out, hs + dec_b, out_bytes);
     return VIT_HIP_OK;
 }
 
