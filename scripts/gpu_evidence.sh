@@ -4,7 +4,7 @@
 #              -> gpurun_out/<tag>_bench_*.json            (copy to profiles/)
 #   profiles : rocprofv3 passes of the same commands (scripts/profile.sh: one --kernel-trace --stats pass + six --pmc passes each)
 #              -> gpurun_out/prof_<tag>_*/                  (scripts/summarize_profile.py turns them into profiles/<tag>_*_summary.md)
-TAG=${1:-r4}; WHAT=${2:-all}
+TAG=${1:-r5}; WHAT=${2:-all}
 mkdir -p gpurun_out
 if [ "$WHAT" = lines ] || [ "$WHAT" = all ]; then
   E=gpurun_out/${TAG}_bench.err; : > $E

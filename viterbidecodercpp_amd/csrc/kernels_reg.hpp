@@ -1272,8 +1272,15 @@ VIT_DEV void reg_chainback_coop_body(const RegChainbackArgs& a) {
 // each, and eight of them plus two of these workgroups must fit a CU -- DAB Radio on the overlapped schedule)
 constexpr int reg_cb_ring_depth(int nreg, int R) { return nreg == 16 ? (R >= 4 ? 2 : VIT_REG_CB_RING_DEPTH_K7) : 8; }
 constexpr int reg_cb_ring_flush_iters(int nreg, int R) { return (nreg == 16 && R >= 4) ? 8 : 16; }
+// the four tiles of a wave's ring slot sit VIT_REG_CB_STAGGER bytes further apart than their 1 KiB rows: with 0 the lanes of the four
+// tiles read the same banks (a lane's byte sits at tile * 1024 + pair * 16 + ...: eight bank groups for 64 lanes; SQ_LDS_BANK_CONFLICT
+// 65 - 74 % of the kernel's LDS-active cycles), with 4 the tiles fall on the banks between
+#ifndef VIT_REG_CB_STAGGER
+#define VIT_REG_CB_STAGGER 0
+#endif
+constexpr unsigned reg_cb_ring_slot_bytes() { return 4096u + 4u * (unsigned)VIT_REG_CB_STAGGER; }
 constexpr unsigned reg_cb_ring_lds_bytes(int nreg, int R) {
-    return (unsigned)reg_cb_ring_depth(nreg, R) * 4096u + (unsigned)reg_cb_ring_flush_iters(nreg, R) * 512u;
+    return (unsigned)reg_cb_ring_depth(nreg, R) * reg_cb_ring_slot_bytes() + (unsigned)reg_cb_ring_flush_iters(nreg, R) * 512u;
 }
 // A step's decisions of a tile are 64 lanes x 16 B / SPS and the chase needs ONE bit per frame of them.  Here the rows never
 // touch a register: the wave streams the 1 KiB rows of FOUR tiles into an LDS ring with direct-to-LDS loads
@@ -1304,10 +1311,10 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
     // limits its occupancy up to the count that enforces that occupancy (40 KiB per one-wave workgroup = one wave per SIMD =
     // .amdhsa_next_free_vgpr 257 for the 22 registers this body uses), and a 264-register wave does not fit beside two update
     // waves.  With the size unknown at compile time the descriptor says what the body needs (tests/test_codegen.py reads it).
-    static_assert(reg_cb_ring_lds_bytes(SP::NREG, SP::R) == D * 4 * 64 * 16 + 2 * KI * 64 * 4, "launch size of the ring kernels");
+    static_assert(reg_cb_ring_lds_bytes(SP::NREG, SP::R) == D * reg_cb_ring_slot_bytes() + 2 * KI * 64 * 4, "launch size of the ring kernels");
     extern __shared__ uint4 reg_cb_dyn_lds[];
     uint4* const ring = reg_cb_dyn_lds;                        // [slot][tile of the wave][lane of the row]
-    u32* const obuf = (u32*)(reg_cb_dyn_lds + D * 4 * 64);     // [frame half][iteration][lane]
+    u32* const obuf = (u32*)((char*)reg_cb_dyn_lds + D * reg_cb_ring_slot_bytes());     // [frame half][iteration][lane]
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef __attribute__((address_space(1))) const void glb_void_t;
     typedef u32 u32_unaligned __attribute__((aligned(1)));
@@ -1326,7 +1333,7 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
     uint8_t* outB = a.out + (size_t)fB * out_stride;
     const uint8_t* my_rows = (const uint8_t*)(a.ws + (size_t)tl * a.ws_tile_stride);   // row of step t at + 1024 (t / SPS)
     const u32 src_off = (u32)lane * 16u;                                                // the row piece this lane moves
-    const u32 pair_base = jt * 1024u + g * 16u;                                         // the pair's q = 0 piece inside a ring slot
+    const u32 pair_base = jt * (1024u + (u32)VIT_REG_CB_STAGGER) + g * 16u;               // the pair's q = 0 piece inside a ring slot
 
     int t = (int)a.L - 1 + SB;                                  // rows are consumed from t = L-1+SB down to SB
     // the output shift register, 32 bits wide: after 32 steps its four bytes are output bytes (reference: the top byte of an
@@ -1378,7 +1385,7 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
             const u32 vo = src_off + (u32)(row < 0 ? 0 : row) * 1024u;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(lds_u8_t*)(uintptr_t)(ring_lds + (u32)(slot * 4 + jj) * 1024u), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(tb[jj] + vo), (lds_void_t*)(lds_u8_t*)(uintptr_t)(ring_lds + (u32)slot * reg_cb_ring_slot_bytes() + (u32)jj * (1024u + (u32)VIT_REG_CB_STAGGER)), 16, 0, 0);
         };
         // t = CT mod 32: row t / SPS sits in slot (CT / SPS) % D in every iteration (an iteration retires ROWS_IT rows, a
         // multiple of D)
@@ -1401,8 +1408,8 @@ VIT_DEV void reg_chainback_ring_body(const RegChainbackArgs& a) {
                     // the row's four loads are the oldest of the 4 D in flight
                     constexpr int NV = 4 * (D - 1);
                     __builtin_amdgcn_s_waitcnt(0x0F70 | (NV & 15) | ((NV >> 4) << 14));   // vmcnt(4 D - 4)
-                    const u32 wA = ring_b[slot * 4096 + sidx * 4 * DW + byte_of(xA, pair_base)];
-                    const u32 wB = ring_b[slot * 4096 + sidx * 4 * DW + 1 + byte_of(xB, pair_base)];
+                    const u32 wA = ring_b[slot * (int)reg_cb_ring_slot_bytes() + sidx * 4 * DW + byte_of(xA, pair_base)];
+                    const u32 wB = ring_b[slot * (int)reg_cb_ring_slot_bytes() + sidx * 4 * DW + 1 + byte_of(xB, pair_base)];
                     if constexpr (ITER % SB == 0) {
                         // the replaced bit's position is a compile-time constant: (SB - (t - pk + 1) % SB) % SB with
                         // t = CT mod SB (SB divides 32)
