@@ -308,11 +308,24 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
+                // (the capped instantiations other than Cassini's 16-bit one keep the nine-instruction form: the select-first form holds
+                // one more value across the symbol loop and they would spill 12 - 16 bytes under their 120-register cap)
+                constexpr bool SELECT_FIRST = !(K == 10 || K == 11 || K == 14 || K == 15) || (RT != 0 && SHIFT == 0);
+                if constexpr (!SELECT_FIRST) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
                 // select by an all-ones / all-zeros mask of the lane's pattern bit (v_bfe_i32 + v_bitop3) instead of v_cmp + v_cndmask
                 const u32 mk = (u32)__builtin_amdgcn_sbfe((int)ln, (u32)i, 1u);
                 e = l2_add(e, __builtin_amdgcn_bitop3_b32(a1, a0, mk, 0xE4));
+                } else {
+                // the lane's EXPECTED symbol first (high where bit i of its pattern is set: an all-ones / all-zeros mask of the bit
+                // picks it, v_bfe_i32 + v_bitop3), then ONE absolute difference: six instructions per symbol where forming both
+                // |high - y| and |low - y| and selecting afterwards took nine (round 4)
+                const u32 mk = (u32)__builtin_amdgcn_sbfe((int)ln, (u32)i, 1u);
+                const u32 c = __builtin_amdgcn_bitop3_b32(HIGH2v, LOW2v, mk, 0xE4);
+                const u32 d = l2_sub(c, y[i]);
+                e = l2_add(e, l2_max_s(d, l2_sub(0u, d)));
+                }
             }
         }
         const uint2 v = make_uint2(e, l2_sub(MAXE2, e));
