@@ -93,7 +93,7 @@ def test_single_rank_line_is_self_consistent():
     assert r["ms_per_step_min"] <= r["ms_per_step_median"] <= r["ms_per_step_max"]
     # the steady-state figure beside the wall-clock one: the same bits priced at the median step
     assert abs(r["value_steady"] - 8192 * 2048 / (r["ms_per_step_median"] * 1e-3) / 1e6) < 1e-6 * r["value_steady"]
-    assert 500 < r["clock_mhz"]["before"] < 3000 and 500 < r["clock_mhz"]["after"] < 3000
+    assert 500 < r["clock_mhz"]["before_warmup"] < 3000 and 500 < r["clock_mhz"]["after"] < 3000
     assert 500 < r["clock_mhz"]["under_load"] < 3000 and r["clock_mhz"]["under_load_probe"]["probe_ms"] < 30
 
 
@@ -109,7 +109,10 @@ def test_headline_line_carries_its_spread_and_both_routes_agree():
     # chainback beside it, the last chainback no update: about one millisecond over the 20 steps) + the first steps' run-in
     assert abs(a["ms_per_step_median"] - a["ms_per_step"]) / a["ms_per_step"] < 0.05, a
     assert a["value"] <= a["value_steady"] * 1.01 and a["value_steady"] < a["value"] * 1.06, (a["value"], a["value_steady"])
-    assert "peak_spec" not in a.get("roofline_valu", {})
+    # the vector-issue roofline is priced against the rate measured on the card; the guide's nominal 2 clocks per instruction
+    # is quoted beside it and is the larger of the two
+    rv = a["roofline_valu"]
+    assert rv["peak_spec"] > rv["peak"] and 0 < rv["frac_of_spec"] < rv["frac"] < 1.0, rv
     assert len(a["ms_per_step_series"]) == 20 and abs(sum(a["ms_per_step_series"]) / 20 - a["ms_per_step"]) < 0.05 * a["ms_per_step"]
     b = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--via", "python"))
     assert b["config"]["via"] == "python"

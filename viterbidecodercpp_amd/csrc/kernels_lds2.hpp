@@ -21,8 +21,12 @@
 //   * add-compare-select in packed 16-bit, exact for wrapping metrics: min = v_pk_min_i16, decision = sign of the signed
 //     SATURATING difference (strict '>' of the reference: a tie keeps predecessor 0).
 //   * decisions: the sign bits of the thread's 16 registers are byte-gathered into one dword per step (frame A in bytes
-//     0/2, frame B in bytes 1/3) and stored ws[pair][step][j]: 4 KiB contiguous per step.  lds2_locate() maps
-//     (step, state) -> (thread, register); vit_hip_export_decisions() converts to the reference bit order.
+//     0/2, frame B in bytes 1/3) and stored ws[pair][block of 4 steps][j][step % 4]: the four dwords of a block that group j
+//     writes sit side by side -- 16 bytes -- because the chainback needs exactly those four per memory round trip (the group
+//     index it reads is the SAME for the four steps of a block, lds2_chainback_kernel), and HBM hands out 64-byte sectors: with
+//     one step per row (round 4) every round trip fetched four sectors for 16 bytes of use, 15.5 x the algorithmic bytes at K = 15.
+//     lds2_locate() maps (step, state) -> (thread, register), lds2_ws_index() (step, thread) -> dword;
+//     vit_hip_export_decisions() converts to the reference bit order.
 //   * renormalisation (new_metric[0] >= threshold, scalar.h:48) after the LAST step of a block is the block-uniform rare
 //     branch it always was (min over registers -> wave scan -> LDS exchange).  After one of the first three steps only
 //     thread 0 can see it (state 0 sits in its register 0): it raises a flag, and behind the barrier the whole workgroup
@@ -82,8 +86,8 @@ VIT_L2 void l2_static_for(F&& f) { l2_static_for_impl(f, std::make_integer_seque
 struct Lds2UpdateArgs {
     const uint8_t* symbols;          // [F][n_steps][R] soft_t
     size_t sym_frame_stride_bytes;
-    u32* ws;                         // [pairs][rows][T] decision dwords
-    size_t ws_pair_stride;           // rows * T
+    u32* ws;                         // [pairs][blocks of 4 steps][G groups][4] decision dwords (lds2_ws_index)
+    size_t ws_pair_stride;           // ceil4(rows) * G dwords
     void* metrics_out;               // [F][N] error_t or null
     uint64_t* renorm_sum;            // [F] or null
     const u32* start_state;          // [F] or null
@@ -115,6 +119,15 @@ __host__ __device__ inline void lds2_locate(u32 s, u32 t, int sbits, u32& j, u32
     const int nlow = (int)(t & 3u) + 1, jb = sbits - 4;
     j = (s >> nlow) & ((1u << jb) - 1u);
     r = ((s & ((1u << nlow) - 1u)) << (4 - nlow)) | (s >> (jb + nlow));
+}
+
+// dword of (trellis step t, group j) inside a frame pair's workspace: blocks of four steps, [block][j][t % 4]; g = groups per step
+// (VIT_L2_WS_GROUPED=0 builds round 4's [step][j] rows for same-box comparisons, scripts/gpu_ab_l2.sh)
+#ifndef VIT_L2_WS_GROUPED
+#define VIT_L2_WS_GROUPED 1
+#endif
+__host__ __device__ inline size_t lds2_ws_index(size_t t, size_t j, size_t g) {
+    return VIT_L2_WS_GROUPED ? (t >> 2) * (4 * g) + j * 4 + (t & 3) : t * g + j;
 }
 
 // LDS index of natural state s inside a metric buffer of n states.  The natural order makes the four ds_write_b128 of a
@@ -483,28 +496,6 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         });
         *wdst = lo4;
     };
-    // stage C of every group of this thread.  The eight table offsets of the stage are unpacked HERE from their packed
-    // registers, once for both groups: the packed words change with every block (the table-set bit is toggled in them), so
-    // the unpacked values cannot be hoisted out of the block loop -- hoisted, they were 32 loop-invariant registers that
-    // the 128-register budget does not have (hipcc spilled 9-22 of them, and every reload's s_waitcnt vmcnt also waited for
-    // the decision stores in flight)
-    u32 tab_set_base = 0;                       // byte offset of the table set the current block reads (0 or SET_TAB)
-    auto stage_all = [&](auto cc, u32* wsp) __attribute__((always_inline)) {   // wsp: decision row of block step 0
-        constexpr int C = decltype(cc)::value;
-        u32 addr[8];
-        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
-            constexpr int h = decltype(hc)::value;
-            addr[h] = tab_set_base + ((h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu));
-        });
-        // the row of this stage: a scalar base per stage (its offset pinned uniform, so that it is not derived from the previous
-        // stage's per-thread address with a 64-bit vector add: rows are 4 KiB apart, beyond the store's immediate offset)
-        u32 row_off = (u32)(C * G);
-        asm volatile("" : "+s"(row_off));          // an SGPR whose value the compiler does not know
-        u32* const row = wsp + row_off;
-        stage(cc, mA, addr, 0u, row + gid);
-        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + gid);
-        __builtin_amdgcn_sched_barrier(0);
-    };
     // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
     constexpr bool SEP = (G / 16) % 8 == 0;     // r*G/16 does not reach the three bits the swizzle touches: base + r*G/4
     // Addresses: ONE byte offset per thread for the 16 / 32 metric reads of a block (register r of group A at +r*G bytes, group
@@ -530,6 +521,44 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
     for (int q = 0; q < NST; ++q) st_off[q] += lds_base;
     auto at = [&](u32 lds_addr) __attribute__((always_inline)) -> lds_char_t* { return (lds_char_t*)(uintptr_t)lds_addr; };
+    // scalar byte base of the 4 G decision dwords of the block that starts at step t0 (a multiple of 4), less what st_off[0]
+    // carries beside 16 g
+    auto ws_base_of = [&](u32 t0) __attribute__((always_inline)) -> char* {
+        return (char*)(ws_pair + (size_t)t0 * G) - (size_t)(MET_OFF + lds_base);
+    };
+    // stage C of every group of this thread.  The eight table offsets of the stage are unpacked HERE from their packed
+    // registers, once for both groups: the packed words change with every block (the table-set bit is toggled in them), so
+    // the unpacked values cannot be hoisted out of the block loop -- hoisted, they were 32 loop-invariant registers that
+    // the 128-register budget does not have (hipcc spilled 9-22 of them, and every reload's s_waitcnt vmcnt also waited for
+    // the decision stores in flight)
+    u32 tab_set_base = 0;                       // byte offset of the table set the current block reads (0 or SET_TAB)
+    auto stage_all = [&](auto cc, char* wsp_b) __attribute__((always_inline)) {   // wsp_b: ws_base_of(first step of the block)
+        constexpr int C = decltype(cc)::value;
+        u32 addr[8];
+        l2_static_for<8>([&](auto hc) __attribute__((always_inline)) {
+            constexpr int h = decltype(hc)::value;
+            addr[h] = tab_set_base + ((h & 1) ? (prow2[C][h >> 1] >> 16) : (prow2[C][h >> 1] & 0xFFFFu));
+        });
+        // this stage's dword of the block: [group][stage] -- group g's four dwords of a block are 16 contiguous bytes (what the
+        // chainback fetches per round trip).  The thread's byte offset 16 g is the loop-carried LDS store address st_off[0] less a
+        // constant, and the constant sits in the block's scalar base (wsp_b): no vector register beyond those the metric stores
+        // hold anyway (a separate 16 g, and 16 (g + T) for the second group, cost the 120-register instantiations 8 - 20 bytes of
+        // scratch).  The stage is an instruction offset; the second group's 16 T bytes go into a scalar base of their own.
+#if VIT_L2_WS_GROUPED
+        l2_opaque(st_off[0]);
+        u32 offB = (u32)(16 * T);
+        asm volatile("" : "+s"(offB));             // an SGPR whose value the compiler does not know
+        stage(cc, mA, addr, 0u, (u32*)(wsp_b + st_off[0]) + C);
+        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, (u32*)((wsp_b + offB) + st_off[0]) + C);
+#else
+        u32 row_off = (u32)(C * G);
+        asm volatile("" : "+s"(row_off));
+        u32* const row = (u32*)(wsp_b + (size_t)(MET_OFF + lds_base)) + row_off;
+        stage(cc, mA, addr, 0u, row + gid);
+        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + gid);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto load_group = [&](u32 (&m)[16], u32 g, u32 off) __attribute__((always_inline)) {
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
@@ -615,7 +644,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) {
             constexpr int C = decltype(cc)::value;
             if (C >= c_first && C < nst) {
-                stage_all(cc, ws_pair + (size_t)t0 * G);
+                stage_all(cc, ws_base_of(t0));
                 // state 0 is register 0 of thread 0's first group after every stage
                 if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
                 __syncthreads();
@@ -648,7 +677,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         // B1, split: "my loads have returned" is announced here (one LDS add per wavefront) ...
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
         lds2_arrive(arrive, lane);
-        u32* const wsp = ws_pair + (size_t)t0 * G;   // uniform: the four decision rows of this block
+        char* const wsp = ws_base_of(t0);           // uniform: the 4 G decision dwords of this block (t0 is a multiple of 4)
 
         l2_static_for<BLK>([&](auto cc) __attribute__((always_inline)) { stage_all(cc, wsp); });
         // ... and awaited only here, four trellis steps later, before the first store: by now every wavefront has long arrived
@@ -699,7 +728,11 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     }
 
     if (a.metrics_out) {
-        for (int s = tid; s < N; s += T) {
+        // an opaque copy of the thread index: the addresses of this once-per-call write-out are functions of it, and formed in
+        // front of the block loop (where hipcc hoists them to) they sit in registers the loop needs -- or in scratch
+        int s_first = tid;
+        asm volatile("" : "+v"(s_first));
+        for (int s = s_first; s < N; s += T) {
             const u32 v = met[lds2_sw((u32)s, (u32)N)] ^ BIAS2;
             if (SHIFT) {
                 ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
@@ -786,7 +819,7 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     const u32 T = (1u << TSB) / 16u;
     const int ignore = TSB < 8 ? TSB : 8;           // ViterbiTracebackBuffer::get_layout (core.h:129-149)
     const int shift_state = 8 - ignore, shift_tail = TSB - ignore, total_bits = TSB + shift_state;
-    const u32* ws = a.ws + (f >> 1) * a.ws_pair_stride;
+    const u32* ws = a.ws + (f >> 1) * a.ws_pair_stride;   // [block][group][step % 4]
     const u32 half = (u32)(f & 1);
     uint8_t* out = a.out + f * (((size_t)a.L + 7) / 8);
     u32 reg = (a.end_state ? (a.end_state[f] & ((1u << TSB) - 1u)) : 0u) << shift_state;
@@ -803,7 +836,7 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     auto load = [&](size_t j, u32 state_j) -> u32 {  // dword of step j + TSB for a survivor whose (known part of the) state is state_j
         const u32 t = (u32)(j + (size_t)TSB);
         const u32 nlow = (t & 3u) + 1u;
-        return ws[(size_t)t * T + ((state_j >> nlow) & jmask)];
+        return ws[lds2_ws_index(t, (state_j >> nlow) & jmask, T)];
     };
     size_t j = a.L;
     // ragged top: single dependent steps down to a step with t % 4 == 3
@@ -814,12 +847,21 @@ __global__ void lds2_chainback_kernel(Lds2ChainbackArgs a) {
     // blocks of four steps: t = j-1+TSB has t % 4 == 3
     while (j >= 4) {
         const u32 s0 = reg >> shift_state;
-        // state k steps back = (s0 >> k) | (newest k bits on top): the slice of step t-k ends at bit (4-k) + K-6 < K-1-k
-        const u32 w0 = load(j - 1, s0), w1 = load(j - 2, s0 >> 1), w2 = load(j - 3, s0 >> 2), w3 = load(j - 4, s0 >> 3);
-        step(j - 1, w0);
-        step(j - 2, w1);
-        step(j - 3, w2);
-        step(j - 4, w3);
+        // state k steps back = (s0 >> k) | (newest k bits on top): the slice of step t-k ends at bit (4-k) + K-6 < K-1-k -- and it
+        // is the SAME slice of s0 for the four steps, bits [4, K-1): one group index, whose four dwords of the block are one
+        // 16-byte load out of one sector
+        const u32 tt = (u32)(j - 1 + (size_t)TSB);               // t % 4 == 3: the block's last step
+#if VIT_L2_WS_GROUPED
+        const uint4 w = *(const uint4*)(ws + lds2_ws_index(tt & ~3u, (s0 >> 4) & jmask, T));
+#else
+        const u32 jj = (s0 >> 4) & jmask;
+        const uint4 w = make_uint4(ws[lds2_ws_index(tt - 3, jj, T)], ws[lds2_ws_index(tt - 2, jj, T)], ws[lds2_ws_index(tt - 1, jj, T)],
+                                   ws[lds2_ws_index(tt, jj, T)]);
+#endif
+        step(j - 1, w.w);
+        step(j - 2, w.z);
+        step(j - 3, w.y);
+        step(j - 4, w.x);
         j -= 4;
     }
     while (j > 0) {
@@ -846,13 +888,13 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
     const u32 w = (u32)(idx % W);
     const u32 t = (u32)((idx / W) % a.n_steps);
     const u32 f = (u32)(idx / ((size_t)W * a.n_steps));
-    const u32* ws = a.ws + (size_t)(f >> 1) * a.ws_pair_stride + (size_t)t * T;
+    const u32* ws = a.ws + (size_t)(f >> 1) * a.ws_pair_stride;
     const u32 half = f & 1u;
     uint64_t word = 0;
     for (u32 b = 0; b < 64; ++b) {
         u32 tj, r;
         lds2_locate(w * 64 + b, t, TSB, tj, r);
-        word |= (uint64_t)((ws[tj] >> lds2_dec_bit(r, half, t & 3u)) & 1u) << b;
+        word |= (uint64_t)((ws[lds2_ws_index(t, tj, T)] >> lds2_dec_bit(r, half, t & 3u)) & 1u) << b;
     }
     a.out[idx] = word;
 }
@@ -860,8 +902,9 @@ __global__ void lds2_export_kernel(Lds2ExportArgs a) {
 // ---- host side ----------------------------------------------------------------------------------------------------
 inline bool lds2_supported(int K, int R) { return K >= 10 && K <= 16 && R >= 1 && R <= 6; }   // 64-entry branch-metric table
 inline size_t lds2_threads(int K) { return ((size_t)1 << (K - 1)) / 16; }
+inline size_t lds2_rows4(int K, size_t L) { return (L + (size_t)K - 1 + 3) / 4 * 4; }          // whole blocks of four steps
 inline size_t lds2_workspace_bytes(int K, size_t frames, size_t L) {
-    return ((frames + 1) / 2) * (L + (size_t)K - 1) * lds2_threads(K) * 4;
+    return ((frames + 1) / 2) * lds2_rows4(K, L) * lds2_threads(K) * 4;
 }
 
 template <int K, int SHIFT>
@@ -928,7 +971,7 @@ inline int lds2_update(int K, int R, const DevConfig& cfg, int shift, const uint
     a.symbols = (const uint8_t*)d_symbols;
     a.sym_frame_stride_bytes = sym_stride * (shift ? 1 : 2);
     a.ws = (u32*)d_ws;
-    a.ws_pair_stride = (L + (size_t)K - 1) * lds2_threads(K);
+    a.ws_pair_stride = lds2_rows4(K, L) * lds2_threads(K);
     a.metrics_out = d_metrics;
     a.renorm_sum = d_renorm;
     a.start_state = d_start;
@@ -949,7 +992,7 @@ inline int lds2_chainback(int K, const void* d_ws, size_t frames, size_t L, uint
     if (frames == 0 || L == 0) return 0;
     Lds2ChainbackArgs a{};
     a.ws = (const u32*)d_ws;
-    a.ws_pair_stride = (L + (size_t)K - 1) * lds2_threads(K);
+    a.ws_pair_stride = lds2_rows4(K, L) * lds2_threads(K);
     a.out = d_out;
     a.end_state = d_end;
     a.frames = (u32)frames;
@@ -963,7 +1006,7 @@ inline int lds2_export(int K, const void* d_ws, size_t frames, size_t n_steps, s
     if (frames == 0 || n_steps == 0) return 0;
     Lds2ExportArgs a{};
     a.ws = (const u32*)d_ws;
-    a.ws_pair_stride = (L + (size_t)K - 1) * lds2_threads(K);
+    a.ws_pair_stride = lds2_rows4(K, L) * lds2_threads(K);
     a.out = d_out;
     a.frames = (u32)frames;
     a.n_steps = (u32)n_steps;

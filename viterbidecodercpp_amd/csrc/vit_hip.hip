@@ -1053,16 +1053,16 @@ const RcclApi* rccl_api() {
 namespace {
 constexpr size_t BROADCAST_STAGING_BYTES = 264 * 1024;      // >= vit_hip_blob_bytes(16, 8, 2, 2)
 struct BroadcastStaging { void* buf[64] = {nullptr}; std::mutex alloc; std::mutex use[64]; };
-BroadcastStaging& broadcast_staging_table() { static BroadcastStaging t; return t; }
+BroadcastStaging* broadcast_staging_table() { static BroadcastStaging t; return &t; }
 // the calling thread has `device` current (DeviceGuard); nullptr if the device index is out of the table or the one-off hipMalloc fails
 void* broadcast_staging(int device) {
     if (device < 0 || device >= 64) return nullptr;
-    BroadcastStaging& t = broadcast_staging_table();
+    BroadcastStaging& t = *broadcast_staging_table();
     std::lock_guard<std::mutex> lock(t.alloc);
     if (!t.buf[device] && hipMalloc(&t.buf[device], BROADCAST_STAGING_BYTES) != hipSuccess) { t.buf[device] = nullptr; (void)hipGetLastError(); }
     return t.buf[device];
 }
-std::mutex& broadcast_staging_mutex(int device) { return broadcast_staging_table().use[device]; }
+std::mutex* broadcast_staging_mutex(int device) { return &broadcast_staging_table()->use[device]; }
 }  // namespace
 
 static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int K, int R, int soft_bytes, int error_bytes,
@@ -1093,7 +1093,7 @@ static int vit_hip_broadcast_table_impl(void* nccl_comm, int root, int rank, int
     if (!d_buf)
         return fail(VIT_HIP_ERR_NO_DEVICE, "no staging buffer on this rank's device BEFORE the broadcast (first call: hipMalloc of 264 KiB failed): abort the communicator, the other ranks are waiting in it");
     // one broadcast at a time per device buffer
-    std::lock_guard<std::mutex> staging_lock(broadcast_staging_mutex(device));
+    std::lock_guard<std::mutex> staging_lock(*broadcast_staging_mutex(device));
     std::string root_error;
     if (rank == root) {
         if (vit_hip_pack_blob(K, R, soft_bytes, error_bytes, branch_table, config, blob.data(), need) != VIT_HIP_OK) {
