@@ -64,9 +64,22 @@ VIT_L2 u32 l2_bfi(u32 mask, u32 a, u32 b) { return __builtin_amdgcn_bitop3_b32(a
 // front of the counter's add, so that neither the compiler nor the memory model may sink those accesses below it (a relaxed
 // add left that to the scheduler's good will).  The fence is restricted to LDS: a generic release would also wait for the
 // decision stores to HBM that are still in flight from the previous block (s_waitcnt vmcnt(0)).
+#ifndef VIT_L2_ASM_ARRIVE
+#define VIT_L2_ASM_ARRIVE 1
+#endif
 VIT_L2 void lds2_arrive(u32* counter, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#if VIT_L2_ASM_ARRIVE
+    // lane 0 alone, by exec mask (every caller runs whole wavefronts): left to the compiler, `if (lane == 0) atomic add` becomes its
+    // wave-wide reduction -- v_mbcnt x 2, v_cmp, a population count, a branch -- for a constant 1
+    (void)lane;
+    u32 addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u32*)counter;
+    u32 one = 1u;
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(addr), "v"(one) : "memory");
+#else
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 // e += d on the lanes of `lanes` only, d wave-uniform: the packed add runs under a temporary exec mask (scalar moves around one
 // VALU instruction; the caller's exec mask is all ones or the code is not reached)
@@ -78,6 +91,28 @@ VIT_L2 u32 l2_add_where(u32 e, u32 d_uniform, uint64_t lanes) {
     return e;
 }
 VIT_L2 void l2_opaque(u32& x) { asm volatile("" : "+v"(x)); }   // the compiler may not assume anything about x across this point
+// LDS accesses spelled out (VIT_L2_ASM_LS): address register + instruction offset and nothing else.  hipcc's own loads and stores
+// want every `base + constant` as a value of its own, hoists those out of the block loop, and the in-loop opaque copies that stop
+// it cost ten v_mov per block (the loop-carried addresses are copied into the block and back).  The compiler does not count these
+// in lgkmcnt: l2_lds_landed() is the wait, and ties the destination registers to it.
+typedef u32 l2_u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 l2_u32x4 __attribute__((ext_vector_type(4)));
+template <int O0, int O1>                                      // offsets in units of 64 dwords
+VIT_L2 l2_u32x2 l2_ds_read2st64(u32 lds_addr) {
+    l2_u32x2 v;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(lds_addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+template <int OFF>
+VIT_L2 void l2_ds_write_b128(u32 lds_addr, l2_u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(lds_addr), "v"(v), "n"(OFF) : "memory");
+}
+VIT_L2 void l2_lds_landed(l2_u32x2 (&p)[8]) {                   // s_waitcnt lgkmcnt(0); nothing below may read p before it
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : : "memory");
+}
+#ifndef VIT_L2_ASM_LS
+#define VIT_L2_ASM_LS 1
+#endif
 template <class F, int... Is>
 VIT_L2 void l2_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -312,8 +347,52 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // Table B (read by the threads' second groups) holds E[p ^ xb] where table A holds E[p] -- a PERMUTATION of the same 64 values:
     // lane p computes E[p] once and stores it twice, at its place in table A and at the place of entry p ^ xb in table B (round 3
     // summed both tables' entries per lane: 6 selects and 6 adds more per table pair)
+#ifndef VIT_L2_SCALAR_BUILD
+#define VIT_L2_SCALAR_BUILD 0
+#endif
     auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB) __attribute__((always_inline)) {
         u32 e = 0;
+        if constexpr (VIT_L2_SCALAR_BUILD != 0) {
+            // EXPERIMENT (-DVIT_L2_SCALAR_BUILD=1): the symbols are wave-uniform, so what does not depend on the lane runs on the scalar
+            // unit -- per symbol and frame b = |low - y|, a = |high - y| (wrapping in 16 bits like soft_t), the base sum of the b and the
+            // deltas a - b -- and lane p adds the deltas of its set bits: ONE packed add per symbol under an exec mask, 8 VALU per
+            // table where the per-lane form takes 34, against ~20 scalar instructions per symbol in front of them
+            const int hi16 = (int)a.cfg.high, lo16 = (int)a.cfg.low;
+            auto absd = [](int expected, int sym) __attribute__((always_inline)) -> u32 {
+                const int d = (int)(int16_t)(uint16_t)(u32)(expected - sym);           // soft_t(expected - sym), wrapping
+                return (u32)(d < 0 ? -d : d);                                          // |-32768| = 0x8000 in the low 16 bits
+            };
+            u32 sA = 0, sB = 0, dl[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (i < R) {
+                    const int yA = (int)(int16_t)(uint16_t)(y[i] & 0xFFFFu), yB = (int)y[i] >> 16;
+                    const u32 aA = absd(hi16, yA), bA = absd(lo16, yA), aB = absd(hi16, yB), bB = absd(lo16, yB);
+                    sA += bA;
+                    sB += bB;
+                    dl[i] = ((aA - bA) & 0xFFFFu) | ((aB - bB) << 16);
+                }
+            }
+            const u32 base = (sA & 0xFFFFu) | (sB << 16);
+            uint64_t save;
+            // lanes with bit i of the lane number set: 0xAAAA.., 0xCCCC.., 0xF0F0.., 0xFF00.., 0xFFFF0000.., the upper half
+            asm volatile(
+                "s_mov_b64 %[sv], exec\n\t"
+                "v_mov_b32 %[e], %[b]\n\t"
+                "s_mov_b32 exec_lo, 0xaaaaaaaa\n\ts_mov_b32 exec_hi, 0xaaaaaaaa\n\tv_pk_add_u16 %[e], %[e], %[d0]\n\t"
+                "s_mov_b32 exec_lo, 0xcccccccc\n\ts_mov_b32 exec_hi, 0xcccccccc\n\tv_pk_add_u16 %[e], %[e], %[d1]\n\t"
+                "s_mov_b32 exec_lo, 0xf0f0f0f0\n\ts_mov_b32 exec_hi, 0xf0f0f0f0\n\tv_pk_add_u16 %[e], %[e], %[d2]\n\t"
+                "s_mov_b32 exec_lo, 0xff00ff00\n\ts_mov_b32 exec_hi, 0xff00ff00\n\tv_pk_add_u16 %[e], %[e], %[d3]\n\t"
+                "s_mov_b32 exec_lo, 0xffff0000\n\ts_mov_b32 exec_hi, 0xffff0000\n\tv_pk_add_u16 %[e], %[e], %[d4]\n\t"
+                "s_mov_b32 exec_lo, 0\n\ts_mov_b32 exec_hi, -1\n\tv_pk_add_u16 %[e], %[e], %[d5]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [e] "=&v"(e), [sv] "=&s"(save)
+                : [b] "s"(base), [d0] "s"(dl[0]), [d1] "s"(dl[1]), [d2] "s"(dl[2]), [d3] "s"(dl[3]), [d4] "s"(dl[4]), [d5] "s"(dl[5]));
+            const uint2 v = make_uint2(e, l2_sub(MAXE2, e));
+            tab[pos] = v;
+            if constexpr (GPT == 2) tab[64 + posB] = v;
+            return;
+        }
         // the lane number is formed again here (two instructions, pinned): kept across the block it is one of the two values the
         // 120-register cap sends to scratch, reloaded behind a full vmcnt(0) right in front of the build
         u32 ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -465,7 +544,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     if constexpr (VECTOR_MASKS >= 3) asm volatile("" : "+v"(M0F));
     // one trellis step on the 16 registers of one group: stage C of a block, table entries at addr[h] + tab_off,
     // decisions of the step -> one dword  (scalar.h:113-134)
-    auto stage = [&](auto cc, u32 (&m)[16], const u32 (&addr)[8], u32 tab_off, u32* wdst) __attribute__((always_inline)) {
+    auto stage = [&](auto cc, u32 (&m)[16], const u32 (&addr)[8], u32 tab_off) __attribute__((always_inline)) -> u32 {
         constexpr int C = decltype(cc)::value, PB = 3 - C;
         // per butterfly: add-compare-select, then its four sign bits straight into the step's decision dword.  v_perm selectors
         // 8..11 replicate a 16-bit half's sign over a byte (clean 0x00 / 0xFF): {A r0, B r0, A r1, B r1}, butterfly h -> bit h
@@ -494,7 +573,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 if constexpr (GPT == 2) __builtin_amdgcn_sched_barrier(0);
             }
         });
-        *wdst = lo4;
+        return lo4;
     };
     // swizzled metric buffer (lds2_sw): read view, register r = state r*G + g; write view, piece q = states 16 g + 4 q ...
     constexpr bool SEP = (G / 16) % 8 == 0;     // r*G/16 does not reach the three bits the swizzle touches: base + r*G/4
@@ -509,6 +588,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // the compile-time-rate instantiation has the registers for all four store offsets; the others carry one and form the rest
     // with a v_xor each
     constexpr int NST = RT ? 4 : 1;
+    constexpr bool ASM_LS = VIT_L2_ASM_LS && SEP && NST == 4 && G % 256 == 0 && (GPT == 1 || T % 256 == 0);   // see load_metrics
     u32 st_off[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)gid ^ (u32)(q << 1));
@@ -545,20 +625,40 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         // hold anyway (a separate 16 g, and 16 (g + T) for the second group, cost the 120-register instantiations 8 - 20 bytes of
         // scratch).  The stage is an instruction offset; the second group's 16 T bytes go into a scalar base of their own.
 #if VIT_L2_WS_GROUPED
-        l2_opaque(st_off[0]);
         u32 offB = (u32)(16 * T);
         asm volatile("" : "+s"(offB));             // an SGPR whose value the compiler does not know
-        stage(cc, mA, addr, 0u, (u32*)(wsp_b + st_off[0]) + C);
-        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, (u32*)((wsp_b + offB) + st_off[0]) + C);
+        if constexpr (ASM_LS) {
+            // spelled out like the metric accesses (the address register is loop invariant there: left to the compiler, its
+            // zero-extension becomes a 64-bit value of its own and every store a 64-bit vector add): scalar base, 32-bit vector
+            // offset, the stage in the offset field.  Not in the compiler's vmcnt: nothing in the kernel waits for a store.
+            const u32 dA = stage(cc, mA, addr, 0u);
+            asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(st_off[0]), "v"(dA), "s"(wsp_b), "n"(4 * C) : "memory");
+            if constexpr (GPT == 2) {
+                const u32 dB = stage(cc, mB, addr, 512u);
+                asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(st_off[0]), "v"(dB), "s"(wsp_b + offB), "n"(4 * C) : "memory");
+            }
+        } else {
+            l2_opaque(st_off[0]);
+            *((u32*)(wsp_b + st_off[0]) + C) = stage(cc, mA, addr, 0u);
+            if constexpr (GPT == 2) *((u32*)((wsp_b + offB) + st_off[0]) + C) = stage(cc, mB, addr, 512u);
+        }
 #else
         u32 row_off = (u32)(C * G);
         asm volatile("" : "+s"(row_off));
         u32* const row = (u32*)(wsp_b + (size_t)(MET_OFF + lds_base)) + row_off;
-        stage(cc, mA, addr, 0u, row + gid);
-        if constexpr (GPT == 2) stage(cc, mB, addr, 512u, row + T + gid);
+        row[gid] = stage(cc, mA, addr, 0u);
+        if constexpr (GPT == 2) row[T + gid] = stage(cc, mB, addr, 512u);
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the compile-time-rate instantiation (Cassini: K = 15, both offsets multiples of 256 bytes) spells its metric loads and stores
+    // out; its five addresses are made opaque ONCE, in front of the block loop
+    if constexpr (ASM_LS) {
+        l2_opaque(ld_addr);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) l2_opaque(st_off[q]);
+    }
+    l2_u32x2 ldA[8], ldB[8];                   // landing pairs of the spelled-out loads: registers 2k, 2k + 1 of a group
     auto load_group = [&](u32 (&m)[16], u32 g, u32 off) __attribute__((always_inline)) {
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
@@ -567,17 +667,46 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         });
     };
     auto load_metrics = [&]() __attribute__((always_inline)) {
+        if constexpr (ASM_LS) {
+            // register r of group A at ld_addr + r G bytes, of group B another T bytes up: r G / 256 and T / 256 in the offset fields
+            l2_static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                ldA[k] = l2_ds_read2st64<(2 * k) * G / 256, (2 * k + 1) * G / 256>(ld_addr);
+                if constexpr (GPT == 2) ldB[k] = l2_ds_read2st64<(2 * k) * G / 256 + T / 256, (2 * k + 1) * G / 256 + T / 256>(ld_addr);
+            });
+            return;
+        }
         u32 t = (u32)gid;
         l2_opaque(ld_addr);
         if constexpr (!SEP) l2_opaque(t);
         load_group(mA, t, ld_addr);
         if constexpr (GPT == 2) load_group(mB, t + (u32)T, ld_addr + (u32)T);      // lds2_sw(g + T) = lds2_sw(g) + T / 4 dwords
     };
+    // "the metric loads (and this wavefront's table writes) have landed": lgkmcnt(0)
+    auto await_metrics = [&]() __attribute__((always_inline)) {
+        if constexpr (ASM_LS) {
+            l2_lds_landed(ldA);
+            if constexpr (GPT == 2) l2_lds_landed(ldB);
+            l2_static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                mA[2 * k] = ldA[k].x;
+                mA[2 * k + 1] = ldA[k].y;
+                if constexpr (GPT == 2) { mB[2 * k] = ldB[k].x; mB[2 * k + 1] = ldB[k].y; }
+            });
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+    };
     auto store_metrics = [&]() __attribute__((always_inline)) {                 // after stage 3: register r holds state 16 g + r
         l2_static_for<4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
             typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) u32x4_t lds_uint4_t;
+            if constexpr (ASM_LS) {
+                l2_ds_write_b128<0>(st_off[q], l2_u32x4{mA[4 * q], mA[4 * q + 1], mA[4 * q + 2], mA[4 * q + 3]});
+                if constexpr (GPT == 2) l2_ds_write_b128<16 * T>(st_off[q], l2_u32x4{mB[4 * q], mB[4 * q + 1], mB[4 * q + 2], mB[4 * q + 3]});
+                return;
+            }
             u32 o;
             if constexpr (NST == 4) {
                 l2_opaque(st_off[q]);
@@ -590,6 +719,8 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             *(lds_uint4_t*)at(o) = u32x4_t{mA[4 * q], mA[4 * q + 1], mA[4 * q + 2], mA[4 * q + 3]};
             if constexpr (GPT == 2) *(lds_uint4_t*)at(o + 16u * (u32)T) = u32x4_t{mB[4 * q], mB[4 * q + 1], mB[4 * q + 2], mB[4 * q + 3]};
         });
+        // the spelled-out stores are not in the compiler's count: the barrier behind them needs the wait written down
+        if constexpr (ASM_LS) __builtin_amdgcn_s_waitcnt(0xC07F);
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
     auto renormalise = [&](u32 need) __attribute__((always_inline)) {
@@ -632,6 +763,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         asm volatile("" : "+v"(tid_o));
         if (c_first == 0) {
             load_metrics();
+            await_metrics();
         } else {                               // mid-block entry: the registers as stage c_first - 1 would have left them
             l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
                 constexpr u32 r = decltype(rc)::value;
@@ -675,7 +807,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         load_metrics();
         tables_build(t0 + BLK, set ^ 1);
         // B1, split: "my loads have returned" is announced here (one LDS add per wavefront) ...
-        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
+        await_metrics();                             // lgkmcnt(0): the 16 / 32 metric loads (and the table writes) are complete
         lds2_arrive(arrive, lane);
         char* const wsp = ws_base_of(t0);           // uniform: the 4 G decision dwords of this block (t0 is a multiple of 4)
 
