@@ -152,6 +152,13 @@ struct RegSpec {
         for (int i = 0; i < R; ++i) p |= parity((v << 1) & G(i)) << i;
         return p;
     }
+    // does any butterfly carry pattern p?  pat() is linear, its image a subspace: a polynomial set that repeats a polynomial (DAB:
+    // 109, 79, 83, 109) reaches only half of the 2^R patterns, and the producer makes no entry for the others
+    static constexpr bool pat_used(u32 p) {
+        for (u32 v = 0; v <= SMASK; ++v)
+            if (pat(v) == p) return true;
+        return false;
+    }
     // position of the decision bit of slot register r (frame half h) inside its decision dword r/16: the sign bits of
     // register pairs (r, r+8) are byte-gathered: byte 0/1 = registers 0-7 of frame A/B, byte 2/3 = registers 8-15 of A/B
     static constexpr u32 dec_bit(u32 r, u32 h) { return (r & 7u) + 8u * h + 16u * ((r >> 3) & 1u); }
@@ -694,6 +701,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     constexpr int j = __builtin_ctz((unsigned)p);
                     waddr[p] = waddr[p & (p - 1)] ^ bm_col[cls][off + j];
                 }
+                if constexpr (SPLIT || SP::pat_used((u32)p)) {      // (whole patterns only: every part of a split pattern occurs)
                 u32 e = (p & 1) ? A1[off] : A0[off];
                 static_for<nb - 1>([&](auto ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(ic)::value + 1;
@@ -702,6 +710,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 char* dst = (char*)bm_ring + waddr[p] + slot0 * ROW * 8 + base * 128;
                 if constexpr (base == 0) *(uint2*)dst = make_uint2(e, pk_sub(MAXE2, e));   // {E, max_error - E} (SPLIT: of the low part)
                 else *(u32*)dst = e;                                                       // the high part's sum alone
+                }
             });
         };
         emit_part(std::integral_constant<int, 0>{}, std::integral_constant<int, RL>{}, std::integral_constant<int, 0>{});
