@@ -134,6 +134,12 @@ def test_update_kernels_leave_room_for_a_chainback_wave(tmp_path, reg_id, cb_all
         assert 8 * usage[k]["lds_static"] + 2 * cb_lds <= 160 * 1024
     cb = [k for k in usage if ("reg_chainback_kernel" if reg_id >= 3 else "reg_chainback_alt_kernel") in k]
     assert len(cb) == 1 and usage[cb[0]]["alloc"] <= cb_alloc and usage[cb[0]]["lds_static"] == 0, usage[cb[0]]
+    if reg_id == 2:
+        # DAB repeats a polynomial (109, 79, 83, 109): 8 of the 16 patterns occur, and the producer writes only those rows of the
+        # ring (RegSpec::pat_used) -- half the entry stores the full set took (192 per kernel)
+        for k in upd:
+            body = _kernel_body(text, re.escape(k))
+            assert body.count("ds_write_b64") + 2 * body.count("ds_write2_b64") <= 110, k
 
 
 def test_k9_chainback_streams_rows_through_lds_and_fits_beside_two_update_waves(tmp_path):
