@@ -103,7 +103,26 @@ public:
         set_traceback_length(0);
     }
     ~ViterbiDecoder_Core() { vit_hip_destroy(m_hip); }
-    ViterbiDecoder_Core(const ViterbiDecoder_Core&) = delete;
+    // Copyable like the reference's class (implicit copy constructor there; assignment is ill-formed there too: a reference and a
+    // const member).  The copy gets a device handle of its own on the same GPU and the source's whole state -- metrics, decision
+    // history, cursor, what is still owed to update()'s return value -- after the source has run whatever it had queued.
+    ViterbiDecoder_Core(const ViterbiDecoder_Core& other) : m_branch_table(other.m_branch_table), m_config(other.m_config) {
+        const_cast<ViterbiDecoder_Core&>(other).flush_pending();
+        vit_hip_info info;
+        viterbi_hip_detail::require_ok(vit_hip_get_info(other.m_hip, &info), "vit_hip_get_info");
+        viterbi_hip_detail::require_ok(
+            vit_hip_create(int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)), m_branch_table.data(), &m_config, info.device,
+                           &m_hip),
+            "vit_hip_create");
+        m_metrics = other.m_metrics;
+        m_decisions = other.m_decisions;
+        const viterbi_hip_detail::FlushHook hook{&ViterbiDecoder_Core::flush_hook, this};
+        m_metrics.set_flush_hook(hook);
+        m_decisions.set_flush_hook(hook);
+        m_current_decoded_bit = other.m_current_decoded_bit;
+        m_unreported_renormalisation = other.m_unreported_renormalisation;
+        m_exact_update_return = other.m_exact_update_return;
+    }
     ViterbiDecoder_Core& operator=(const ViterbiDecoder_Core&) = delete;
 
     // number of decoded (information) bits kept for traceback; the K-1 tail steps are added on top

@@ -95,9 +95,9 @@ int main() {
         HIP_OK(hipMemcpy(b.data(), d_out3, b.size(), hipMemcpyDeviceToHost));
         if (memcmp(a.data(), b.data(), a.size()) != 0) { printf("pipeline ordered by events: bytes differ from the serial decode\nFAIL\n"); return 1; }
         pipe.sync();
-        hipEventDestroy(ready); hipEventDestroy(done); hipStreamDestroy(producer); hipStreamDestroy(consumer);
-        hipFree(d_sym2); hipFree(d_out3);
-        hipFree(d_out2);
+        (void)hipEventDestroy(ready); (void)hipEventDestroy(done); (void)hipStreamDestroy(producer); (void)hipStreamDestroy(consumer);
+        (void)hipFree(d_sym2); (void)hipFree(d_out3);
+        (void)hipFree(d_out2);
     }
 
     // one decoder shared by two host threads, as the reference shares one branch table between the Cores of its worker

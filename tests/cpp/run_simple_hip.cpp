@@ -50,6 +50,23 @@ int main() {
                double(total_input_bits) / us[10]);
     }
 
+    // a decoder is copyable, as in the reference: a copy taken in mid-frame carries the whole state and finishes the frame on its own
+    {
+        const size_t half = (total_input_bits / 2) * R;
+        vitdec.reset();
+        uint64_t err_a = Decoder::template update<uint64_t>(vitdec, symbols.data(), half);
+        auto twin = vitdec;
+        uint64_t err_b = err_a;
+        err_a += Decoder::template update<uint64_t>(vitdec, symbols.data() + half, symbols.size() - half);
+        err_b += Decoder::template update<uint64_t>(twin, symbols.data() + half, symbols.size() - half);
+        std::vector<uint8_t> rx_a(total_input_bytes), rx_b(total_input_bytes);
+        vitdec.chainback(rx_a.data(), total_input_bits);
+        twin.chainback(rx_b.data(), total_input_bits);
+        const bool same = rx_a == rx && rx_b == rx && err_a == err_b && vitdec.get_error() == twin.get_error();
+        printf("copy in mid-frame: %s\n", same ? "identical" : "DIFFERENT");
+        if (!same) return 1;
+    }
+
     const size_t total_errors = count_bit_errors(tx, rx);
     printf("%zu/%zu incorrect bits\n", total_errors, total_input_bits);
     if (total_errors > 0 || error != 0) {
