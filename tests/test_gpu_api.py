@@ -29,8 +29,8 @@ def test_plan_selection_and_errors():
     assert dec.plan == _lib.PLAN_LDS2
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_LDS) == _lib.OK
-    # K=8, R=3 has neither: served by the LDS plan, the others refused
-    code = Code("custom", 8, 3, (0o367, 0o331, 0o225))
+    # K=6, R=5 has neither (split pattern tables need the four-lane layout of K >= 7): served by the LDS plan, the others refused
+    code = Code("custom", 6, 5, (0o65, 0o57, 0o75, 0o53, 0o71))
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_LDS
@@ -45,6 +45,7 @@ def test_plan_selection_and_errors():
     (7, 5, (0o171, 0o133, 0o165, 0o117, 0o135), "SOFT8"),
     (9, 6, (0o557, 0o663, 0o711, 0o561, 0o753, 0o715), "SOFT16"),
     (9, 5, (0o557, 0o663, 0o711, 0o561, 0o753), "HARD8"),
+    (8, 6, (0o371, 0o247, 0o367, 0o331, 0o225, 0o313), "SOFT16"),     # K = 8: split tables + the sub-chunk fetch (253 registers, no scratch)
 ])
 def test_rate_5_and_6_codes_on_the_register_plan(oracle, K, R, G, decode_type):
     """R = 5, 6 at K = 7, 9: run-time compiled register-plan instantiations with SPLIT pattern tables (low / high part, two packed
@@ -199,6 +200,8 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     (6, 4, (0o65, 0o57, 0o75, 0o53), "HARD8"),
     (8, 2, (0o371, 0o247), "SOFT16"),        # K = 8: 32 registers per lane over 4 lanes, a decision row holds two steps
     (8, 2, (0o371, 0o247), "SOFT8"),
+    (8, 3, (0o367, 0o331, 0o225), "SOFT16"),   # K = 8 with 8 / 16 patterns (round 5: PLAN_LDS before): branch metrics per sub-chunk, as at K = 9
+    (8, 4, (0o371, 0o247, 0o367, 0o331), "HARD8"),
 ])
 def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     """polynomials outside the ahead-of-time table: PLAN_REG is compiled for them on first use (reg_jit.hpp) and must
@@ -296,7 +299,7 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     ((11, 2, (0o3345, 0o3613)), "SOFT16", 40, 128, (2, 1, 1)),    # K = 11: the same
     ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 1)),  # K = 13 (144 registers allocated, three waves per SIMD by LDS: 3 x 144 + 24 of 512): overlapped too -- the descriptor rule; 8192 x 4096: 16.4 -> 16.0 ms per batch
     ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 1)),   # K = 10 (PLAN_LDS2 since round 5, capped at 120 registers): overlapped
-    ((8, 3, (0o367, 0o331, 0o225)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 8, R = 3 (PLAN_LDS: no register-plan instantiation): back to back
+    ((8, 3, (0o367, 0o331, 0o225)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 8, R = 3 (PLAN_LDS as long as nobody asks for the run-time compiled register plan): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 4: 224 registers with the sub-chunk branch-metric fetch (368 before: sub-batches), 8 KiB of LDS per wave
     (3, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 7, R = 3 (LTE): update capped at 240 registers: 2 x 240 + 32

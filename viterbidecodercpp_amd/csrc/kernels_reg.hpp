@@ -417,7 +417,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // K = 9, R = 3, 4: branch metrics fetched per sub-chunk of four butterflies instead of per step (RegChunk).  Their LDS ring
     // holds ONE group of four steps (8 KiB per wave at R = 4, so that eight update waves and two 40 KiB chainback workgroups share
     // a CU): the next group is produced INSIDE a group's last step, right behind the last fetch of the old one
-    constexpr bool BMCHUNK = LDSBM && !SP::X3 && NREG >= 64 && NP >= 8;
+    constexpr bool BMCHUNK = LDSBM && !SP::X3 && ((NREG >= 64 && NP >= 8) || (NREG >= 32 && NP >= 16));
     using RC = RegChunk<SP>;
     // R = 5, 6: the pattern is split into a low and a high part with a table each (RegSpec::SPLIT): NPROW entries per step
     constexpr bool SPLIT = SP::SPLIT;

@@ -37,10 +37,11 @@ namespace vit {
 // K = 6 keeps all 32 states of a frame pair in one lane; its unrolled block is lcm(5, 16 / gcd(16, R * sizeof(soft_t))) steps,
 // which only stays reasonable (<= 40) for R = 2 and R = 4
 inline bool reg_jit_supported(int K, int R) {
-    if (K == 6) return R == 2 || R == 4;
-    if (K == 8) return R == 1 || R == 2;      // the 28-step block of 7 state bits only keeps its LDS ring whole for <= 4 patterns
-    if ((K == 7 || K == 9) && (R == 5 || R == 6)) return true;   // split pattern tables (RegSpec::SPLIT)
-    return (K == 3 || K == 4 || K == 5 || K == 7 || K == 9) && R >= 1 && R <= 4;
+    // R = 5, 6: split pattern tables (RegSpec::SPLIT), a feature of the LDS branch-metric ring (four lanes per frame pair: K >= 7).
+    // K = 8 with eight patterns and more fetches its branch metrics per sub-chunk like K = 9 (one group of four steps in the ring)
+    if (K >= 7 && K <= 9) return R >= 1 && R <= 6;
+    if (K == 6) return R == 2 || R == 4;      // (odd rates: five state bits and an odd symbol stride unroll a 240-step block, minutes of hipcc)
+    return K >= 3 && K <= 5 && R >= 1 && R <= 4;
 }
 
 namespace jit_detail {
@@ -135,9 +136,11 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 }  // namespace jit_detail
 
 // returns nullptr and fills `err` on failure.  The module belongs to the current device.
-inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int device, std::string& err) {
+// one code object per (code, symbol width): a decoder handle has ONE width, and the update / resume kernels of the other one are
+// half of the compile time (1 - 4 minutes for the K = 8, 9 codes)
+inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shift, int device, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K in {3,4,5} with R <= 4, K in {7,9} with R <= 6, K = 6 with R = 2 or 4, K = 8 with R <= 2"; return nullptr; }
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 3..5 with R <= 4, K = 6 with R = 2 or 4, K = 7..9 with R <= 6"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");
@@ -162,7 +165,7 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
     std::ostringstream key;
     key << "reg_K" << K << "R" << R;
     for (int i = 0; i < 6; ++i) key << "_" << (i < R ? G[i] : 0u);
-    key << "_" << arch << "_" << std::hex << h;
+    key << (shift ? "_s8" : "_s16") << "_" << arch << "_" << std::hex << h;
     const std::string mkey = key.str() + "@" + std::to_string(device);
     auto it = modules().find(mkey);
     if (it != modules().end()) return it->second;
@@ -182,10 +185,10 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
               << "using SP = vit::RegSpec<" << K << ", " << R;
             for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
             f << ", " << lane_bits << ", " << (4 < R ? G[4] : 0u) << "u, " << (5 < R ? G[5] : 0u) << "u>;\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, false>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, false>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_16(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 0, true>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_8(vit::RegUpdateArgs a) { vit::reg_update_body<SP, 8, true>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_" << (shift ? 8 : 16)
+              << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, " << (shift ? 8 : 0) << ", false>(a); }\n"
+              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_" << (shift ? 8 : 16) << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, "
+              << (shift ? 8 : 0) << ", true>(a); }\n"
               << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_min_waves<SP>()) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
               << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
             if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_alt(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";
@@ -202,10 +205,8 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int devi
     }
     RegJitModule* m = new RegJitModule();
     if (!private_to_user(hsaco, false) || hipModuleLoad(&m->module, hsaco.c_str()) != hipSuccess ||
-        hipModuleGetFunction(&m->update[0], m->module, "vit_jit_update_16") != hipSuccess ||
-        hipModuleGetFunction(&m->update[1], m->module, "vit_jit_update_8") != hipSuccess ||
-        hipModuleGetFunction(&m->resume[0], m->module, "vit_jit_resume_16") != hipSuccess ||
-        hipModuleGetFunction(&m->resume[1], m->module, "vit_jit_resume_8") != hipSuccess ||
+        hipModuleGetFunction(&m->update[shift ? 1 : 0], m->module, shift ? "vit_jit_update_8" : "vit_jit_update_16") != hipSuccess ||
+        hipModuleGetFunction(&m->resume[shift ? 1 : 0], m->module, shift ? "vit_jit_resume_8" : "vit_jit_resume_16") != hipSuccess ||
         hipModuleGetFunction(&m->chainback, m->module, "vit_jit_chainback") != hipSuccess ||
         hipModuleGetFunction(&m->export_, m->module, "vit_jit_export") != hipSuccess) {
         err = "could not load " + hsaco;
