@@ -103,6 +103,12 @@ VIT_L2 l2_u32x2 l2_ds_read2st64(u32 lds_addr) {
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(lds_addr), "n"(O0), "n"(O1) : "memory");
     return v;
 }
+template <int O0, int O1>                                      // offsets in dwords
+VIT_L2 l2_u32x2 l2_ds_read2_b32(u32 lds_addr) {
+    l2_u32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(lds_addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
 template <int OFF>
 VIT_L2 void l2_ds_write_b128(u32 lds_addr, l2_u32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(lds_addr), "v"(v), "n"(OFF) : "memory");
@@ -536,7 +542,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // more spills (12 - 28 bytes of scratch, reloads inside the block)
 #ifndef VIT_L2_VECTOR_MASKS
     constexpr bool CAPPED = K == 10 || K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
-    constexpr int VECTOR_MASKS = CAPPED ? (RT != 0 ? 2 : 0) : 3;
+    constexpr int VECTOR_MASKS = CAPPED && GPT == 2 ? (RT != 0 ? 2 : 0) : K == 10 ? 2 : 3;   // (K = 10, 11: one group per thread, registers to spare)
 #else
     constexpr int VECTOR_MASKS = VIT_L2_VECTOR_MASKS;
 #endif
@@ -589,6 +595,15 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // with a v_xor each
     constexpr int NST = RT ? 4 : 1;
     constexpr bool ASM_LS = VIT_L2_ASM_LS && SEP && NST == 4 && G % 256 == 0 && (GPT == 1 || T % 256 == 0);   // see load_metrics
+    // K = 10, 11 (G = 32, 64 groups): register r's G bytes reach into the bits the swizzle folds q into, so lds2_sw(r G + g) is not
+    // "base + r G" -- but it is for the registers that agree in r mod NB (NB = 4, 2): NB per-thread bases, the rest of r in the
+    // offset field, and the 16 loads of a block are eight ds_read2_b32 with no address arithmetic (the compiler's form recomputed
+    // the swizzle per register and block: 99 of the 683 vector instructions a K = 11 block took)
+    constexpr bool ASM_LD_SMALL = VIT_L2_ASM_LS && !SEP && GPT == 1 && (G == 32 || G == 64);
+    constexpr int NB = G == 32 ? 4 : 2;
+    u32 ld_base[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) ld_base[k] = MET_OFF + 4u * lds2_sw((u32)(k * G) + (u32)gid, (u32)N);
     u32 st_off[NST];
 #pragma unroll
     for (int q = 0; q < NST; ++q) st_off[q] = MET_OFF + 4u * (u32)(q * (N / 4)) + 16u * ((u32)gid ^ (u32)(q << 1));
@@ -658,6 +673,13 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
         for (int q = 0; q < NST; ++q) l2_opaque(st_off[q]);
     }
+    if constexpr (ASM_LD_SMALL) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            ld_base[k] += lds_base;
+            l2_opaque(ld_base[k]);
+        }
+    }
     l2_u32x2 ldA[8], ldB[8];                   // landing pairs of the spelled-out loads: registers 2k, 2k + 1 of a group
     auto load_group = [&](u32 (&m)[16], u32 g, u32 off) __attribute__((always_inline)) {
         l2_static_for<16>([&](auto rc) __attribute__((always_inline)) {
@@ -673,6 +695,14 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 constexpr int k = decltype(kc)::value;
                 ldA[k] = l2_ds_read2st64<(2 * k) * G / 256, (2 * k + 1) * G / 256>(ld_addr);
                 if constexpr (GPT == 2) ldB[k] = l2_ds_read2st64<(2 * k) * G / 256 + T / 256, (2 * k + 1) * G / 256 + T / 256>(ld_addr);
+            });
+            return;
+        }
+        if constexpr (ASM_LD_SMALL) {
+            l2_static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int r_lo = (k / NB) * 2 * NB + (k % NB), r_hi = r_lo + NB;      // the same base: r_lo = r_hi (mod NB)
+                ldA[k] = l2_ds_read2_b32<(r_lo - r_lo % NB) * G / 4, (r_hi - r_hi % NB) * G / 4>(ld_base[r_lo % NB]);
             });
             return;
         }
@@ -692,6 +722,14 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 mA[2 * k] = ldA[k].x;
                 mA[2 * k + 1] = ldA[k].y;
                 if constexpr (GPT == 2) { mB[2 * k] = ldB[k].x; mB[2 * k + 1] = ldB[k].y; }
+            });
+        } else if constexpr (ASM_LD_SMALL) {
+            l2_lds_landed(ldA);
+            l2_static_for<8>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int r_lo = (k / NB) * 2 * NB + (k % NB), r_hi = r_lo + NB;
+                mA[r_lo] = ldA[k].x;
+                mA[r_hi] = ldA[k].y;
             });
         } else {
             __builtin_amdgcn_s_waitcnt(0xC07F);
