@@ -21,6 +21,8 @@ CASES = [
     (COMMON_CODES[6], [_lib.PLAN_REG]),
     (Code("K10", 10, 2, (0o1167, 0o1545)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
     (Code("K11", 11, 2, (0o3345, 0o3613)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),
+    (Code("K10R5", 10, 5, (0o1167, 0o1545, 0o1117, 0o1365, 0o1633)), [_lib.PLAN_LDS2]),      # two table passes per block
+    (Code("K11R6", 11, 6, (0o3345, 0o3613, 0o2671, 0o3175, 0o2353, 0o3661)), [_lib.PLAN_LDS2]),   # four
     (COMMON_CODES[7], [_lib.PLAN_LDS2]),
     # K = 16: one 1024-thread workgroup per CU, 128 KiB of metrics updated in place; the LDS plan reads its patterns from L2
     (Code("K16", 16, 2, (46749, 58851)), [_lib.PLAN_LDS2, _lib.PLAN_LDS]),

@@ -36,13 +36,17 @@ def test_auto_plan_matrix(oracle, code, decode_type):
 
 @pytest.mark.parametrize("decode_type", DECODE_TYPES)
 @pytest.mark.parametrize("K,R,G", [(10, 2, (0o1167, 0o1545)), (10, 3, (0o1117, 0o1365, 0o1633)), (11, 2, (0b10011011001, 0b11110110101)), (13, 3, (0o10533, 0o10675, 0o17661)),
-                                   (12, 2, (0o4335, 0o5723)), (14, 2, (0o21645, 0o35661)), (15, 6, COMMON_CODES[7].G)])
+                                   (12, 2, (0o4335, 0o5723)), (14, 2, (0o21645, 0o35661)), (15, 6, COMMON_CODES[7].G),
+                                   # one-wavefront workgroups build their tables in passes over (step, pattern): one pass at R <= 4, two at
+                                   # R = 5, four at R = 6 (the later ones fetch their symbols when they run)
+                                   (10, 4, (0o1167, 0o1545, 0o1117, 0o1365)), (10, 5, (0o1167, 0o1545, 0o1117, 0o1365, 0o1633)),
+                                   (11, 6, (0o3345, 0o3613, 0o2671, 0o3175, 0o2353, 0o3661)), (11, 5, (0o3345, 0o3613, 0o2671, 0o3175, 0o2353))])
 def test_lds2_plan_large_k(oracle, K, R, G, decode_type):
     """PLAN_LDS2 (packed frame pair in LDS) on K = 10..15 (K = 10: 32 group slots, lanes 32 - 63 mirror them), including
     non-stock polynomials; odd frame count; long enough to renormalise."""
     from viterbidecodercpp_amd import Code
     code = Code(f"K{K}R{R}", K, R, tuple(G))
-    dec = check_batch_against_oracle(oracle, code, decode_type, 3, 48 if K >= 14 else 1600 if K == 10 else 128, -2.0 if K >= 14 else 2.0, seed=K,
+    dec = check_batch_against_oracle(oracle, code, decode_type, 3, 48 if K >= 14 else 1600 if K == 10 and R <= 3 else 200 if R >= 4 else 128, -2.0 if K >= 14 else 2.0, seed=K,
                                      plan=_lib.PLAN_LDS2)
     assert dec.plan == _lib.PLAN_LDS2
     dec2 = check_batch_against_oracle(oracle, code, decode_type, 2, 40, 1.0, seed=K + 1, plan=_lib.PLAN_LDS)

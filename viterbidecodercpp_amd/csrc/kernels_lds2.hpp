@@ -356,7 +356,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #ifndef VIT_L2_SCALAR_BUILD
 #define VIT_L2_SCALAR_BUILD 0
 #endif
-    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB) __attribute__((always_inline)) {
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB, bool valid = true) __attribute__((always_inline)) {
         u32 e = 0;
         if constexpr (VIT_L2_SCALAR_BUILD != 0) {
             // EXPERIMENT (-DVIT_L2_SCALAR_BUILD=1): the symbols are wave-uniform, so what does not depend on the lane runs on the scalar
@@ -408,7 +408,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             if (i < R) {
                 // (the capped instantiations other than Cassini's 16-bit one keep the nine-instruction form: the select-first form holds
                 // one more value across the symbol loop and they would spill 12 - 16 bytes under their 120-register cap)
-                constexpr bool SELECT_FIRST = !(K == 10 || K == 11 || K == 14 || K == 15) || (RT != 0 && SHIFT == 0);
+                constexpr bool SELECT_FIRST = !(K == 14 || K == 15) || (RT != 0 && SHIFT == 0);
                 if constexpr (!SELECT_FIRST) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
                 const u32 a1 = l2_max_s(d1, l2_sub(0u, d1)), a0 = l2_max_s(d0, l2_sub(0u, d0));
@@ -427,7 +427,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             }
         }
         const uint2 v = make_uint2(e, l2_sub(MAXE2, e));
-        tab[pos] = v;
+        if (valid) tab[pos] = v;                 // (always true but in the pass form below, where a lane's step may lie outside the chunk)
         if constexpr (GPT == 2) tab[64 + posB] = v;
     };
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
@@ -435,12 +435,15 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
     // closing barrier) and are moved to SGPRs right behind it (tables_commit), so that no vector register carries them through
     // the block's compute phase -- at 128 registers per thread every one of them was a spill.
-    u32 yland[CPW][6];                       // lds2_supported(): R <= 6
+    u32 yland[(NW == 1 && GPT == 1 && RT == 0) ? 1 : CPW][6];   // lds2_supported(): R <= 6 (one-wavefront workgroups: pass 0 only, see PASSES)
     u32 ysym[CPW][6];                        // wave-uniform
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { yland[i][k] = 0; ysym[i][k] = 0; }
+        for (int k = 0; k < 6; ++k) {
+            if (i < (int)(sizeof(yland) / sizeof(yland[0]))) yland[i][k] = 0;
+            ysym[i][k] = 0;
+        }
     u32 tabpos[CPW];                         // where this lane's entry goes in the tables this wavefront builds (lds2_tab_index)
     u32 tabxorB[CPW];                        // ... and, XORed onto it, where it goes in table B: the map is linear, index(p ^ xb) = index(p) ^ index(xb); wave-uniform
 #pragma unroll
@@ -456,8 +459,36 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // unit (s_pack_ll / s_pack_hh) -- happens on the building wavefronts only; round 3 packed in vector registers (14 instructions)
     // and broadcast (6) on all eight.
     constexpr bool RAW = RT != 0 && SHIFT == 0 && RT % 2 == 0;
+    // ONE-WAVEFRONT workgroups (K = 10, 11) build all four tables of a block themselves -- a 64-entry table per step, of which a
+    // rate-1/2 code uses four entries.  There the lanes are dealt out over (step, pattern) instead: with E = max(16, 2^R) entries per
+    // table a pass of the build serves 64 / E steps at once -- all four at R <= 4, two at R = 5 -- and the block needs 1, 2 or 4 passes
+    // (R = 6: the old one table per pass).  A lane's step differs from its neighbours' now, so the symbols stay in VECTOR registers
+    // (each lane loads its own step's: no broadcast to SGPRs) and a lane whose step lies outside the chunk skips its store.
+    constexpr bool PASSES = NW == 1 && GPT == 1 && RT == 0;
+    const int lgE = R <= 4 ? 4 : R;                                 // wave-uniform
+    const int n_pass = PASSES ? 1 << (lgE - 4) : 0;                 // 1, 2, 4
+    // the block step this lane serves in pass j is pass_step(j) = j * (64 / E) + lane / E; where its entry goes: pass_pos(j) -- kept in
+    // a register for pass 0 (the only pass of every code with R <= 4), formed again in the later passes of an R = 5, 6 code (four
+    // more loop-invariant registers send the kernel to scratch, with a reload behind a full vmcnt(0) in every block)
+    u32 pass_c0 = (u32)lane >> lgE;
+    auto pass_step = [&](int j) __attribute__((always_inline)) -> u32 { return (((u32)j << (6 - lgE)) + pass_c0) & (u32)(BLK - 1); };
+    auto pass_pos = [&](int j) __attribute__((always_inline)) -> u32 {
+        const u32 cc = pass_step(j);
+        const u32 f = cc == 0 ? a.idx_f[0] : cc == 1 ? a.idx_f[1] : cc == 2 ? a.idx_f[2] : a.idx_f[3];
+        const u32 t = cc == 0 ? a.idx_t[0] : cc == 1 ? a.idx_t[1] : cc == 2 ? a.idx_t[2] : a.idx_t[3];
+        // entry of the lane's pattern inside the table of ITS step (tables of a set: BLK x 64 entries)
+        return cc * 64u + lds2_tab_index((u32)lane & ((1u << lgE) - 1u), f, t);
+    };
+    if constexpr (PASSES) tabpos[0] = pass_pos(0);
     const bool builder = wave < BLK;                 // wave-uniform (wave comes from v_readfirstlane)
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
+        if constexpr (PASSES) {                                     // pass 0 only: the later passes of an R = 5, 6 code fetch when they run
+            u32 ts = t0 + pass_step(0);
+            ts = ts < t_begin ? t_begin : ts;
+            ts = ts >= t_end ? t_end - 1u : ts;
+            load_syms(ts, yland[0]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             // unconditional, from a step clamped into the chunk [t_begin, t_end): what a clamped step fetches is never used
@@ -478,6 +509,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         }
     };
     auto tables_commit = [&]() __attribute__((always_inline)) {
+        if constexpr (PASSES) return;                               // the symbols are per lane: nothing to broadcast
         if constexpr (RAW) {
             if (NW > BLK && !builder) return;        // only SGPRs are written here
 #pragma unroll
@@ -497,6 +529,26 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         }
     };
     auto tables_build = [&](u32 t0, int set) __attribute__((always_inline)) {   // from the symbols loaded by tables_load(t0)
+        if constexpr (PASSES) {
+            {
+                const u32 ts = t0 + pass_step(0);
+                build_table(etab + (size_t)(set * BLK) * 64, yland[0], tabpos[0], 0u, ts < t_end && ts >= t_begin);
+            }
+            // R = 5, 6: one or three more passes, each fetching its symbols on the spot (the other wavefronts of the SIMD cover the
+            // wait; symbols of four passes held a block ahead are 18 registers the 120-register kernel does not have) -- a real loop,
+            // so that nothing of a later pass becomes a loop-invariant register of the block loop
+#pragma nounroll
+            for (int j = 1; j < n_pass; ++j) {
+                const u32 ts = t0 + pass_step(j);
+                const bool valid = ts < t_end && ts >= t_begin;
+                u32 tc = ts < t_begin ? t_begin : ts;
+                tc = tc >= t_end ? t_end - 1u : tc;
+                u32 y[6] = {0, 0, 0, 0, 0, 0};
+                load_syms(tc, y);
+                build_table(etab + (size_t)(set * BLK) * 64, y, pass_pos(j), 0u, valid);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + NW * i;
@@ -542,7 +594,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // more spills (12 - 28 bytes of scratch, reloads inside the block)
 #ifndef VIT_L2_VECTOR_MASKS
     constexpr bool CAPPED = K == 10 || K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
-    constexpr int VECTOR_MASKS = CAPPED && GPT == 2 ? (RT != 0 ? 2 : 0) : K == 10 ? 2 : 3;   // (K = 10, 11: one group per thread, registers to spare)
+    constexpr int VECTOR_MASKS = CAPPED && GPT == 2 ? (RT != 0 ? 2 : 0) : 3;      // (K = 10, 11: one group per thread, registers to spare)
 #else
     constexpr int VECTOR_MASKS = VIT_L2_VECTOR_MASKS;
 #endif
