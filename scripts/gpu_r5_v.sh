@@ -10,4 +10,5 @@ $T 11 2 1845,1995 SOFT16 32768 8192 6
 $T 10 2 1005,755 HARD8 32768 8192 6
 $T 11 2 1845,1995 SOFT8 32768 8192 6
 $T 12 2 2787,3645 SOFT16 4096 8192 6
+$T 12 2 2787,3645 SOFT16 16384 8192 6
 } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/v_k10_k11.log

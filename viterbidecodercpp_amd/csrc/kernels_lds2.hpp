@@ -435,7 +435,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
     // closing barrier) and are moved to SGPRs right behind it (tables_commit), so that no vector register carries them through
     // the block's compute phase -- at 128 registers per thread every one of them was a spill.
-    u32 yland[(NW == 1 && GPT == 1 && RT == 0) ? 1 : CPW][6];   // lds2_supported(): R <= 6 (one-wavefront workgroups: pass 0 only, see PASSES)
+    u32 yland[(NW <= 2 && GPT == 1 && RT == 0) ? 1 : CPW][6];   // lds2_supported(): R <= 6 (one-wavefront workgroups: pass 0 only, see PASSES)
     u32 ysym[CPW][6];                        // wave-uniform
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
@@ -464,14 +464,19 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // table a pass of the build serves 64 / E steps at once -- all four at R <= 4, two at R = 5 -- and the block needs 1, 2 or 4 passes
     // (R = 6: the old one table per pass).  A lane's step differs from its neighbours' now, so the symbols stay in VECTOR registers
     // (each lane loads its own step's: no broadcast to SGPRs) and a lane whose step lies outside the chunk skips its store.
-    constexpr bool PASSES = NW == 1 && GPT == 1 && RT == 0;
-    const int lgE = R <= 4 ? 4 : R;                                 // wave-uniform
-    const int n_pass = PASSES ? 1 << (lgE - 4) : 0;                 // 1, 2, 4
+    // (K = 12, two wavefronts of two steps each, does the same with E >= 32: one pass up to R = 5)
+    constexpr bool PASSES = NW <= 2 && GPT == 1 && RT == 0;
+    constexpr int SPW = BLK / (NW <= 2 ? NW : 1);                   // steps a wavefront serves: 4, 2
+    constexpr int LGE_MIN = SPW == 4 ? 4 : 5;                       // 64 / SPW lanes per step at most
+    const int lgE = R <= LGE_MIN ? LGE_MIN : R;                     // wave-uniform
+    const int n_pass = PASSES ? SPW >> (6 - lgE) : 0;               // 1, 2, 4
     // the block step this lane serves in pass j is pass_step(j) = j * (64 / E) + lane / E; where its entry goes: pass_pos(j) -- kept in
     // a register for pass 0 (the only pass of every code with R <= 4), formed again in the later passes of an R = 5, 6 code (four
     // more loop-invariant registers send the kernel to scratch, with a reload behind a full vmcnt(0) in every block)
     u32 pass_c0 = (u32)lane >> lgE;
-    auto pass_step = [&](int j) __attribute__((always_inline)) -> u32 { return (((u32)j << (6 - lgE)) + pass_c0) & (u32)(BLK - 1); };
+    auto pass_step = [&](int j) __attribute__((always_inline)) -> u32 {
+        return ((u32)(wave * SPW) + ((u32)j << (6 - lgE)) + pass_c0) & (u32)(BLK - 1);
+    };
     auto pass_pos = [&](int j) __attribute__((always_inline)) -> u32 {
         const u32 cc = pass_step(j);
         const u32 f = cc == 0 ? a.idx_f[0] : cc == 1 ? a.idx_f[1] : cc == 2 ? a.idx_f[2] : a.idx_f[3];
