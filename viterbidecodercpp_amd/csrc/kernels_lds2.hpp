@@ -406,8 +406,9 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
-                // (the capped instantiations other than Cassini's 16-bit one keep the nine-instruction form: the select-first form holds
-                // one more value across the symbol loop and they would spill 12 - 16 bytes under their 120-register cap)
+                // (the two-groups-per-thread capped instantiations other than Cassini's 16-bit one -- K = 14, K = 15 at other rates or 8-bit --
+                // keep the nine-instruction form: the select-first form holds one more value across the symbol loop and they would
+                // spill 12 - 16 bytes under their 120-register cap)
                 constexpr bool SELECT_FIRST = !(K == 14 || K == 15) || (RT != 0 && SHIFT == 0);
                 if constexpr (!SELECT_FIRST) {
                 const u32 d1 = l2_sub(HIGH2v, y[i]), d0 = l2_sub(LOW2v, y[i]);
@@ -593,10 +594,10 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // the bit-field-insert masks of the decision gather in VECTOR registers: v_bitop3_b32 with three VGPR operands issues in 2.7
     // clocks, with a scalar operand in 4.7 (profiles/r4_op_rates.txt); opaque, or the optimiser folds them back into SGPR literals
     u32 M55 = 0x55555555u, M33 = 0x33333333u, M0F = 0x0F0F0F0Fu;
-    // how many of them: all three where registers allow (K = 12, 13, 16); under the 120-register cap (K = 11, 14, 15) the Cassini
-    // instantiation carries 0x55.. and 0x33.. (six of a gather's seven inserts) in the two registers its table build gives up
-    // (`high` / `low` stay scalar there: a v_mov per symbol on the four building wavefronts) and the others none -- a register
-    // more spills (12 - 28 bytes of scratch, reloads inside the block)
+    // how many of them: all three where registers allow (K = 10 ... 13, 16); under the 120-register cap with two groups per thread
+    // (K = 14, 15) the Cassini instantiation carries 0x55.. and 0x33.. (six of a gather's seven inserts) in the two registers its
+    // table build gives up (`high` / `low` stay scalar there: a v_mov per symbol on the four building wavefronts) and the others
+    // none -- a register more spills (12 - 28 bytes of scratch, reloads inside the block)
 #ifndef VIT_L2_VECTOR_MASKS
     constexpr bool CAPPED = K == 10 || K == 11 || K == 14 || K == 15;          // lds2_update_is_capped()
     constexpr int VECTOR_MASKS = CAPPED && GPT == 2 ? (RT != 0 ? 2 : 0) : 3;      // (K = 10, 11: one group per thread, registers to spare)
@@ -978,12 +979,12 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 
 template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) lds2_update_kernel(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
-// The same body capped at 120 registers (the attribute counts in halves of the unified file), used for K = 11, 14, 15: four
+// The same body capped at 120 registers (the attribute counts in halves of the unified file), used for K = 10, 11, 14, 15: four
 // 125..128-register waves fill a SIMD's 512, four 120-register ones leave 32 -- the chainback kernel's 24, which then runs
-// beside the next batch's update instead of behind it.  All of them fit the cap without scratch (the 8-bit Cassini
-// instantiation alone pays 16 bytes) once the table build forms its lane number afresh instead of keeping it; alone the capped
-// Cassini kernel is 0.6 % slower (49.2 -> 49.5 ms), the overlap hides 2.3 ms of chainback: 51.6 -> 50.1 - 50.3 ms per 4096 x 8192
-// batch.  (K = 12 needs 98 registers anyway; K = 13 and 16 would spill.)
+// beside the next batch's update instead of behind it.  All of them fit the cap without scratch (tests/test_codegen.py); round 3:
+// alone the capped Cassini kernel was 0.6 % slower (49.2 -> 49.5 ms), the overlap hid 2.3 ms of chainback: 51.6 -> 50.1 - 50.3 ms per
+// 4096 x 8192 batch.  (K = 10, 11 use 96 - 110 registers since their symbols stay per lane; K = 12 needs 96 anyway; K = 13 and 16
+// would spill.)
 template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) __attribute__((amdgpu_num_vgpr(60)))
 lds2_update_kernel_c120(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
