@@ -1,15 +1,16 @@
 // kernels_lds2.hpp -- PLAN_LDS2: large constraint lengths (K = 10..16, any polynomials): one workgroup per frame PAIR,
-// state metrics of both frames packed in one u32 per state and double-buffered in LDS, FOUR trellis steps per barrier.
+// state metrics of both frames packed in one u32 per state in ONE LDS buffer updated in place, FOUR trellis steps per barrier.
 //
 // Device implementation of the reference's scalar strategy
 //   ViterbiDecoder_Scalar::update / bfly / renormalise   include/viterbi/viterbi_decoder_scalar.h:29-153
 //   ViterbiDecoder_Core::chainback                       include/viterbi/viterbi_decoder_core.h:214-236
 // bit-identical to PLAN_LDS; this is the plan that makes K = 15 (Cassini, 16384 states) worth running on the GPU.
 //
-// Mapping (gfx950, wave64), N = 2^(K-1) states, T = N/16 threads (1024 at K = 15), JB = K-5 bits of thread index j:
-//   * LDS: two metric buffers of N u32 = (frame A metric | frame B metric << 16), both biased by 0x8000 so that the
-//     reference's unsigned compare is a SIGNED compare here (2 x 64 KiB at K = 15), plus two sets of four 64-entry
-//     branch-metric tables {E[p], max_error - E[p]}.
+// Mapping (gfx950, wave64), N = 2^(K-1) states in G = N/16 radix-16 groups, one or two groups per thread (Lds2Geom: 512 threads at
+// K = 15), JB = K-5 bits of group index j:
+//   * LDS: ONE metric buffer of N u32 = (frame A metric | frame B metric << 16), both biased by 0x8000 so that the
+//     reference's unsigned compare is a SIGNED compare here (64 KiB at K = 15; updated in place, see lds2_update_body), plus two
+//     sets of four 64-entry branch-metric tables {E[p], max_error - E[p]}.
 //   * radix-16 block: thread j loads the 16 states [r | j] (r = 0..15 in the TOP four index bits: lane-consecutive dwords,
 //     conflict free) and runs FOUR trellis steps on them in registers.  Stage c pairs the registers that differ in bit 3-c
 //     (their states differ in the top bit: a butterfly) and writes the two results back in place, so after stage c
@@ -17,7 +18,8 @@
 //     stores its 16 new metrics as four ds_write_b128.  One workgroup barrier and one pass over the metric buffers per
 //     FOUR steps (the one-step-per-barrier version spent 57 % of its cycles waiting).
 //   * the 4 x 8 branch patterns of a thread are loop invariant: LDS byte offsets into the step's table, one ds_read_b64 per
-//     butterfly.  The four tables of block b+1 are built during block b (wavefront c builds step c; lane p makes entry p).
+//     butterfly.  The four tables of block b+1 are built during block b (wavefront c builds step c, lane p makes entry p; the
+//     one- and two-wavefront workgroups of K = 10, 11, 12 deal their lanes out over (step, pattern) instead: PASSES).
 //   * add-compare-select in packed 16-bit, exact for wrapping metrics: min = v_pk_min_i16, decision = sign of the signed
 //     SATURATING difference (strict '>' of the reference: a tie keeps predecessor 0).
 //   * decisions: the sign bits of the thread's 16 registers are byte-gathered into one dword per step (frame A in bytes
@@ -29,8 +31,8 @@
 //     vit_hip_export_decisions() converts to the reference bit order.
 //   * renormalisation (new_metric[0] >= threshold, scalar.h:48) after the LAST step of a block is the block-uniform rare
 //     branch it always was (min over registers -> wave scan -> LDS exchange).  After one of the first three steps only
-//     thread 0 can see it (state 0 sits in its register 0): it raises a flag, and behind the barrier the whole workgroup
-//     re-runs that block stage by stage with the reduction in between (about once per 1000 steps).
+//     thread 0 can see it (state 0 sits in its register 0): the update is in place, so that case is PREDICTED from a bound on
+//     metric[0] and the block then runs stage by stage with the reduction in between (slow_block; about once per 1000 steps).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
