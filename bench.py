@@ -284,7 +284,7 @@ def cpu_baseline(code_id, code, pc, decode_type, sym_dev, L, target_seconds):
     return res
 
 
-def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, out_dev, F, L, n=64):
+def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, out_dev, F, L, n=512):
     """n frames of the timed batch against the reference SCALAR decoder (oracle/_ref; the C restatement where that is
     absent): chainback bytes AND every decision word."""
     import numpy as np
@@ -293,7 +293,7 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
 
     dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[decode_type]
     ocfg = pyoracle.stock_config(dt, code.R)
-    n = max(1, min(F, n if code.K < 11 else 2))
+    n = max(1, min(F, n if code.K < 11 else 8))            # (the scalar reference decodes ~12 Mbit/s at K = 7, ~0.1 at K = 15: a second or so)
     S = L + code.K - 1
     # the workspace layout is tile-major: export the first frames of the last launch only (with sub-batches that launch holds
     # frames f0 .. of the batch)
