@@ -42,7 +42,9 @@ def test_auto_plan_matrix(oracle, code, decode_type):
                                    (10, 4, (0o1167, 0o1545, 0o1117, 0o1365)), (10, 5, (0o1167, 0o1545, 0o1117, 0o1365, 0o1633)),
                                    (11, 6, (0o3345, 0o3613, 0o2671, 0o3175, 0o2353, 0o3661)), (11, 5, (0o3345, 0o3613, 0o2671, 0o3175, 0o2353)),
                                    # K = 12: two wavefronts of two steps each -- one pass up to R = 5, two at R = 6
-                                   (12, 5, (0o4335, 0o5723, 0o6265, 0o7173, 0o5537)), (12, 6, (0o4335, 0o5723, 0o6265, 0o7173, 0o5537, 0o6747))])
+                                   (12, 5, (0o4335, 0o5723, 0o6265, 0o7173, 0o5537)), (12, 6, (0o4335, 0o5723, 0o6265, 0o7173, 0o5537, 0o6747)),
+                                   # K = 13: the same with two groups per thread (a permuted table B beside every table)
+                                   (13, 6, (0o10533, 0o10675, 0o17661, 0o13271, 0o15353, 0o16475)), (13, 2, (0o10533, 0o17661))])
 def test_lds2_plan_large_k(oracle, K, R, G, decode_type):
     """PLAN_LDS2 (packed frame pair in LDS) on K = 10..15 (K = 10: 32 group slots, lanes 32 - 63 mirror them), including
     non-stock polynomials; odd frame count; long enough to renormalise."""

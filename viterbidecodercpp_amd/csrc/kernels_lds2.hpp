@@ -430,15 +430,17 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             }
         }
         const uint2 v = make_uint2(e, l2_sub(MAXE2, e));
-        if (valid) tab[pos] = v;                 // (always true but in the pass form below, where a lane's step may lie outside the chunk)
-        if constexpr (GPT == 2) tab[64 + posB] = v;
+        if (valid) {                             // (always true but in the pass form below, where a lane's step may lie outside the chunk)
+            tab[pos] = v;
+            if constexpr (GPT == 2) tab[64 + posB] = v;
+        }
     };
     // wavefront w builds the tables of block steps c = w, w + NW, ... (< BLK); symbols are fetched one block ahead
     constexpr int CPW = GM::CPW;
     // The symbols of a step are the same for every lane: they land in VGPRs (vector loads, issued just before a block's
     // closing barrier) and are moved to SGPRs right behind it (tables_commit), so that no vector register carries them through
     // the block's compute phase -- at 128 registers per thread every one of them was a spill.
-    u32 yland[(NW <= 2 && GPT == 1 && RT == 0) ? 1 : CPW][6];   // lds2_supported(): R <= 6 (one-wavefront workgroups: pass 0 only, see PASSES)
+    u32 yland[(NW <= 2 && RT == 0) ? 1 : CPW][6];   // lds2_supported(): R <= 6 (one-wavefront workgroups: pass 0 only, see PASSES)
     u32 ysym[CPW][6];                        // wave-uniform
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
@@ -468,7 +470,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // (R = 6: the old one table per pass).  A lane's step differs from its neighbours' now, so the symbols stay in VECTOR registers
     // (each lane loads its own step's: no broadcast to SGPRs) and a lane whose step lies outside the chunk skips its store.
     // (K = 12, two wavefronts of two steps each, does the same with E >= 32: one pass up to R = 5)
-    constexpr bool PASSES = NW <= 2 && GPT == 1 && RT == 0;
+    constexpr bool PASSES = NW <= 2 && RT == 0;                     // K = 10, 11, 12 and (two groups per thread: a table B per step) 13
     constexpr int SPW = BLK / (NW <= 2 ? NW : 1);                   // steps a wavefront serves: 4, 2
     constexpr int LGE_MIN = SPW == 4 ? 4 : 5;                       // 64 / SPW lanes per step at most
     const int lgE = R <= LGE_MIN ? LGE_MIN : R;                     // wave-uniform
@@ -484,10 +486,21 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         const u32 cc = pass_step(j);
         const u32 f = cc == 0 ? a.idx_f[0] : cc == 1 ? a.idx_f[1] : cc == 2 ? a.idx_f[2] : a.idx_f[3];
         const u32 t = cc == 0 ? a.idx_t[0] : cc == 1 ? a.idx_t[1] : cc == 2 ? a.idx_t[2] : a.idx_t[3];
-        // entry of the lane's pattern inside the table of ITS step (tables of a set: BLK x 64 entries)
-        return cc * 64u + lds2_tab_index((u32)lane & ((1u << lgE) - 1u), f, t);
+        // entry of the lane's pattern inside the table of ITS step (tables of a set: BLK x GPT x 64 entries)
+        return cc * (u32)(GPT * 64) + lds2_tab_index((u32)lane & ((1u << lgE) - 1u), f, t);
     };
-    if constexpr (PASSES) tabpos[0] = pass_pos(0);
+    // ... and, XORed onto it, where the same sum goes in the step's table B (two groups per thread): index(p ^ xb) = index(p) ^ index(xb)
+    auto pass_xorB = [&](int j) __attribute__((always_inline)) -> u32 {
+        const u32 cc = pass_step(j);
+        const u32 f = cc == 0 ? a.idx_f[0] : cc == 1 ? a.idx_f[1] : cc == 2 ? a.idx_f[2] : a.idx_f[3];
+        const u32 t = cc == 0 ? a.idx_t[0] : cc == 1 ? a.idx_t[1] : cc == 2 ? a.idx_t[2] : a.idx_t[3];
+        const u32 xb = cc == 0 ? xorB[0] : cc == 1 ? xorB[1] : cc == 2 ? xorB[2] : xorB[3];
+        return lds2_tab_index(xb, f, t);
+    };
+    if constexpr (PASSES) {
+        tabpos[0] = pass_pos(0);
+        if constexpr (GPT == 2) tabxorB[0] = pass_xorB(0);          // per lane here (the other form keeps it wave-uniform)
+    }
     const bool builder = wave < BLK;                 // wave-uniform (wave comes from v_readfirstlane)
     auto tables_load = [&](u32 t0) __attribute__((always_inline)) {     // symbols of block starting at t0
         if constexpr (PASSES) {                                     // pass 0 only: the later passes of an R = 5, 6 code fetch when they run
@@ -540,7 +553,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         if constexpr (PASSES) {
             {
                 const u32 ts = t0 + pass_step(0);
-                build_table(etab + (size_t)(set * BLK) * 64, yland[0], tabpos[0], 0u, ts < t_end && ts >= t_begin);
+                build_table(etab + (size_t)(set * BLK) * GPT * 64, yland[0], tabpos[0], tabpos[0] ^ tabxorB[0], ts < t_end && ts >= t_begin);
             }
             // R = 5, 6: one or three more passes, each fetching its symbols on the spot (the other wavefronts of the SIMD cover the
             // wait; symbols of four passes held a block ahead are 18 registers the 120-register kernel does not have) -- a real loop,
@@ -553,7 +566,8 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 tc = tc >= t_end ? t_end - 1u : tc;
                 u32 y[6] = {0, 0, 0, 0, 0, 0};
                 load_syms(tc, y);
-                build_table(etab + (size_t)(set * BLK) * 64, y, pass_pos(j), 0u, valid);
+                const u32 pj = pass_pos(j);
+                build_table(etab + (size_t)(set * BLK) * GPT * 64, y, pj, GPT == 2 ? pj ^ pass_xorB(j) : 0u, valid);
             }
             return;
         }
