@@ -202,6 +202,7 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     (8, 2, (0o371, 0o247), "SOFT8"),
     (8, 3, (0o367, 0o331, 0o225), "SOFT16"),   # K = 8 with 8 / 16 patterns (round 5: PLAN_LDS before): branch metrics per sub-chunk, as at K = 9
     (8, 4, (0o371, 0o247, 0o367, 0o331), "HARD8"),
+    (6, 3, (0o65, 0o57, 0o75), "SOFT8"),       # K = 6 at an odd rate: a 240-step unrolled block
 ])
 def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     """polynomials outside the ahead-of-time table: PLAN_REG is compiled for them on first use (reg_jit.hpp) and must

@@ -40,8 +40,7 @@ inline bool reg_jit_supported(int K, int R) {
     // R = 5, 6: split pattern tables (RegSpec::SPLIT), a feature of the LDS branch-metric ring (four lanes per frame pair: K >= 7).
     // K = 8 with eight patterns and more fetches its branch metrics per sub-chunk like K = 9 (one group of four steps in the ring)
     if (K >= 7 && K <= 9) return R >= 1 && R <= 6;
-    if (K == 6) return R == 2 || R == 4;      // (odd rates: five state bits and an odd symbol stride unroll a 240-step block, minutes of hipcc)
-    return K >= 3 && K <= 5 && R >= 1 && R <= 4;
+    return K >= 3 && K <= 6 && R >= 1 && R <= 4;   // (K = 6 at an odd rate: five state bits and an odd symbol stride unroll a 240-step block)
 }
 
 namespace jit_detail {
@@ -140,7 +139,7 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 // half of the compile time (1 - 4 minutes for the K = 8, 9 codes)
 inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shift, int device, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 3..5 with R <= 4, K = 6 with R = 2 or 4, K = 7..9 with R <= 6"; return nullptr; }
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 3..6 with R <= 4 and K = 7..9 with R <= 6"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");
