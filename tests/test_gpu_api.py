@@ -29,8 +29,8 @@ def test_plan_selection_and_errors():
     assert dec.plan == _lib.PLAN_LDS2
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_LDS) == _lib.OK
-    # K=6, R=5 has neither (split pattern tables need the four-lane layout of K >= 7): served by the LDS plan, the others refused
-    code = Code("custom", 6, 5, (0o65, 0o57, 0o75, 0o53, 0o71))
+    # K=6, R=7 has neither (no fast plan reads more than six symbols per step): served by the LDS plan, the others refused
+    code = Code("custom", 6, 7, (0o65, 0o57, 0o75, 0o53, 0o71, 0o47, 0o77))
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_LDS
@@ -203,6 +203,8 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     (8, 3, (0o367, 0o331, 0o225), "SOFT16"),   # K = 8 with 8 / 16 patterns (round 5: PLAN_LDS before): branch metrics per sub-chunk, as at K = 9
     (8, 4, (0o371, 0o247, 0o367, 0o331), "HARD8"),
     (6, 3, (0o65, 0o57, 0o75), "SOFT8"),       # K = 6 at an odd rate: a 240-step unrolled block
+    (5, 5, (0o27, 0o31, 0o33, 0o37, 0o35), "SOFT16"),   # R = 5, 6 below K = 7: every sum formed in the lane, no table to split
+    (6, 6, (0o65, 0o57, 0o75, 0o53, 0o71, 0o47), "HARD8"),
 ])
 def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     """polynomials outside the ahead-of-time table: PLAN_REG is compiled for them on first use (reg_jit.hpp) and must

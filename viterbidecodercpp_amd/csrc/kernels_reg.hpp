@@ -117,7 +117,7 @@ struct RegSpec {
     // low RL polynomials and the high R - RL each get their own table (8 + 4 or 8 + 8 entries: the ring of an R = 4 code), and
     // the consumer forms E[p] = Elo[p_lo] + Ehi[p_hi], max_error - E[p] = (max_error - Elo[p_lo]) - Ehi[p_hi] with two packed
     // instructions per butterfly.  Everything below that speaks of "a part" means the bit range [off, off + n) of the pattern.
-    static constexpr bool SPLIT = R_ > 4;
+    static constexpr bool SPLIT = R_ > 4 && LANE_BITS_ == 2;     // (K < 7: every sum is formed in the lane, no table to split)
     static constexpr int RL = SPLIT ? 3 : R_, RH = R_ - RL;      // polynomials of the low / high part
     static constexpr int NPL = 1 << RL, NPH = SPLIT ? 1 << RH : 0;
     // table entries per step and frame pair: a power of two (R = 5: 8 + 4 padded to 16), because the producer forms its write
