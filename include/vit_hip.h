@@ -71,7 +71,7 @@ extern "C" {
 /* kernel plans (vit_hip_set_plan): which device implementation serves update()/chainback() */
 #define VIT_HIP_PLAN_AUTO 0
 #define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
-#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 3..9, R <= 6).
+#define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 2..9, R <= 6).
                                The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32

@@ -204,6 +204,8 @@ def test_batch_calls_capture_into_a_hip_graph(oracle):
     (8, 4, (0o371, 0o247, 0o367, 0o331), "HARD8"),
     (6, 3, (0o65, 0o57, 0o75), "SOFT8"),       # K = 6 at an odd rate: a 240-step unrolled block
     (5, 5, (0o27, 0o31, 0o33, 0o37, 0o35), "SOFT16"),   # R = 5, 6 below K = 7: every sum formed in the lane, no table to split
+    (2, 2, (0o3, 0o1), "SOFT16"),              # K = 2: two states, one butterfly
+    (2, 3, (0o3, 0o2, 0o3), "HARD8"),
     (6, 6, (0o65, 0o57, 0o75, 0o53, 0o71, 0o47), "HARD8"),
 ])
 def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):

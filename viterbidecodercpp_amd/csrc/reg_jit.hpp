@@ -42,7 +42,7 @@ inline bool reg_jit_supported(int K, int R) {
     if (K >= 7 && K <= 9) return R >= 1 && R <= 6;
     // K < 7: the whole state of a frame pair sits in one lane and every branch metric is summed there (no table to split); K = 6 at an
     // odd rate unrolls a 240-step block, K = 6 at R = 6 runs out of registers (644 bytes of scratch) and is still far ahead of PLAN_LDS
-    return K >= 3 && K <= 6 && R >= 1 && R <= 6;
+    return K >= 2 && K <= 6 && R >= 1 && R <= 6;
 }
 
 namespace jit_detail {
@@ -141,7 +141,7 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 // half of the compile time (1 - 4 minutes for the K = 8, 9 codes)
 inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shift, int device, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 3..9 with R <= 6"; return nullptr; }
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 2..9 with R <= 6"; return nullptr; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");

@@ -405,7 +405,7 @@ const char* vit_hip_plan_note(vit_hip_handle h) {
         else if (!h->linear)
             note += "; no faster plan: the branch table is not that of a linear convolutional code";
         else
-            note += "; no faster plan exists for this (K, R): the register plan serves K = 3..9 with R <= 6, PLAN_LDS2 K = 10..16 with R <= 6";
+            note += "; no faster plan exists for this (K, R): the register plan serves K = 2..9 with R <= 6, PLAN_LDS2 K = 10..16 with R <= 6";
     }
     return note.c_str();
 }
@@ -430,7 +430,7 @@ static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
         g_last_error.clear();
         if (!guard.ok || !try_reg_jit(h))
             return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG not available for this code: " +
-                        (g_last_error.empty() ? std::string("K must be 3..9 and R <= 6, linear branch table") : g_last_error));
+                        (g_last_error.empty() ? std::string("K must be 2..9 and R <= 6, linear branch table") : g_last_error));
     }
     if (plan == VIT_HIP_PLAN_LDS2 && !h->lds2_ok)
         return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_LDS2 serves K = 10..16 with R <= 6 and a linear branch table (see kernels_lds2.hpp)");
