@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the contract's timed region: an UNTIMED-for-`value` leg of back-to-back submits lasting at least this "
                          "long with per-batch timing on -> value_sustained, the decimated step series, first/last-100 medians (0: skip)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="the default workload (BASELINE configs[1]) at N=1 is followed by configs[2], [3] (one GPU's share) and [4] "
+                         "through the same pipeline API, reported as `configs: [...]` in the same JSON line (the reference runs its "
+                         "whole matrix in one invocation: examples/run_benchmark.cpp:168-179); this flag leaves them out")
     ap.add_argument("--parity", action="store_true", help="run the in-run parity check against the scalar reference even with --no-cpu-baseline")
     ap.add_argument("--synth", default="hip", choices=["hip", "torch"],
                     help="frame synthesis (untimed): hip = vit_hip_synth_batch (one HIP kernel), torch = ATen elementwise ops")
@@ -284,6 +288,20 @@ def cpu_baseline(code_id, code, pc, decode_type, sym_dev, L, target_seconds):
     return res
 
 
+def collective_library(backend):
+    """what carried the N > 1 run's collectives: torch's "nccl" backend IS RCCL on ROCm -- its version as the runtime reports it"""
+    import torch
+
+    if backend != "nccl":
+        return {"name": backend, "version": None}
+    try:
+        v = torch.cuda.nccl.version()
+        v = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        v = f"unknown ({type(e).__name__})"
+    return {"name": "RCCL (torch.distributed backend \"nccl\")", "version": v, "hip": getattr(torch.version, "hip", None)}
+
+
 def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, out_dev, F, L, n=512):
     """n frames of the timed batch against the reference SCALAR decoder (oracle/_ref; the C restatement where that is
     absent): chainback bytes AND every decision word."""
@@ -291,6 +309,7 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
     import torch
     from oracle import pyoracle
 
+    pyoracle.ensure_built()
     dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[decode_type]
     ocfg = pyoracle.stock_config(dt, code.R)
     n = max(1, min(F, n if code.K < 11 else 8))            # (the scalar reference decodes ~12 Mbit/s at K = 7, ~0.1 at K = 15: a second or so)
@@ -315,6 +334,127 @@ def reference_parity(code_id, code, pc, decode_type, last_decisions, sym_dev, ou
     torch.cuda.synchronize()
     return {"frames_checked_vs_scalar_reference": int(n), "first_frame_checked": int(f0), "checker": "reference (oracle/_ref)" if ref else "port (oracle/)",
             "chainback_bytes_bit_exact": bool(ok_b), "decision_words_bit_exact": bool(ok_d), "bit_exact": bool(ok_b and ok_d)}
+
+
+def run_case(cfg_index, steps, warmup, local_rank, dev, sustain_seconds=1.0):
+    """One more BASELINE config after the headline, through the same shipped pipeline API (vit_hip_pipeline_submit per step): its own
+    decoder, synthetic batch and workspaces, freed before the next one.  Returns the compact record that goes into `configs: [...]`:
+    value (wall clock over the K timed steps), value_steady (median step), value_sustained (median step of a further untimed
+    leg), per-launch kernel times from the pipeline's HIP events, the HBM roofline of the update kernel, the vector-issue roofline
+    where profiles/traffic.json has an instruction count for this launch, and parity of the last timed launch against the scalar
+    reference (bytes and every decision word; 64 frames, 8 at K >= 11)."""
+    import gc
+
+    import numpy as np
+    import torch
+
+    from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, DecodePipeline, ViterbiBranchTable, ViterbiDecoder_Config, _lib, get_decoding_config
+
+    t_case = time.perf_counter()
+    code_id, decode_type, F, L, ebn0 = BASELINE_CONFIGS[cfg_index]
+    code = COMMON_CODES[code_id]
+    pc = get_decoding_config(decode_type, code.R)
+    S, W, sb = L + code.K - 1, code.decision_words, pc.soft_bytes
+    table = ViterbiBranchTable(code.K, code.R, code.G, pc.soft_decision_high, pc.soft_decision_low, pc.soft_dtype)
+    dec = BatchDecoder(table, ViterbiDecoder_Config.from_decoder_config(pc), device=local_rank)
+    tx, sym = dec.synth(F, L, ebn0, seed=1, first_frame=0)
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device=dev)
+    pipe = DecodePipeline(dec, F, L)
+    sch = pipe.schedule
+    NUPD = int(sch.update_streams)
+    F_launch = min(F, int(sch.sub_batch_frames))
+    per_step = -(-F // F_launch)
+    pipe.set_timing(True)
+    for _ in range(warmup):
+        pipe.submit(sym, out)
+    pipe.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.submit(sym, out)
+    pipe.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t_upd, t_cb, t_done = pipe.timing()
+    n_warm = warmup * per_step
+    t_done = t_done.astype(np.float64)
+    upd_ms, cb_ms = float(np.mean(t_upd[n_warm:])), float(np.mean(t_cb[n_warm:]))
+    t_start = t_done[n_warm - 1] if n_warm else 0.0
+    step_times = np.diff(np.concatenate([[t_start], t_done[n_warm:][per_step - 1::per_step]]))
+    step_median = float(np.median(step_times))
+    # parity of the last TIMED launch, before anything else writes the workspaces
+    parity = reference_parity(code_id, code, pc, decode_type, pipe.export_last_decisions, sym, out, F, L, n=64)
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=dev)
+    ber = int(lut[torch.bitwise_xor(out, tx).long()].sum().item()) / float(F * L)
+    # sustained leg (untimed for `value`): back-to-back submits for >= sustain_seconds, median completion-to-completion step
+    sustained_median = None
+    if sustain_seconds > 0:
+        chunk = max(8, int(250.0 / max(step_median, 0.05)))
+        pipe.set_timing(True)
+        t_begin, n = time.perf_counter(), 0
+        while time.perf_counter() - t_begin < sustain_seconds or n < 2 * chunk:
+            for _ in range(chunk):
+                pipe.submit(sym, out)
+            n += chunk
+            pipe.sync()
+        _, _, d = pipe.timing()
+        st = np.diff(d.astype(np.float64)[per_step - 1::per_step])
+        keep = np.ones(len(st), dtype=bool)
+        keep[chunk - 1::chunk] = False                      # the first step after each sync carries the pipeline refill
+        sustained_median = float(np.median(st[keep]))
+    upd_bytes_launch = F_launch * (S * code.R * sb + S * W * 8)
+    upd_bytes = F * (S * code.R * sb + S * W * 8)
+    cb_bytes = F * (L * 8 + L // 8)
+    achieved = upd_bytes_launch / (upd_ms * 1e-3) / 1e9
+    step_ms = elapsed / steps * 1e3
+    traffic = valu_insts = traffic_src = None
+    key = f"{code.name}|{decode_type}|{F_launch}x{L}|{_lib.PLAN_NAMES[dec.plan]}"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {})
+        traffic, valu_insts = tj.get("update_kernel_hbm_bytes_per_launch"), tj.get("update_kernel_valu_insts_per_launch")
+        traffic_src = f"{tj.get('source')} (builder's rocprofv3 --pmc run of `bench.py --config {cfg_index}`; not measured by this run)" if tj else None
+    except (OSError, ValueError):
+        pass
+    rec = {
+        "baseline_config": cfg_index,
+        "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {decode_type} ({'u16/s16' if sb == 2 else 'u8/s8'}), {F} frames x {L} info bits"
+                               + (" (one GPU's share of the 8-GPU run of 262144 frames)" if cfg_index == 3 else "") + f", AWGN Eb/N0={ebn0} dB",
+                   "frames_per_gpu": F, "bits_per_frame": L, "plan": _lib.PLAN_NAMES[dec.plan], "via": "pipeline",
+                   "pipeline": f"{int(sch.workspaces)} workspaces, {NUPD} update stream(s), chainback "
+                               f"{'beside the next update' if sch.chainback_overlapped else 'back to back'}"
+                               + (f", {per_step} sub-batches of {F_launch} frames" if per_step > 1 else "")},
+        "dtype": "u16" if pc.error_bytes == 2 else "u8", "unit": "Mbit/s", "steps": steps, "warmup": warmup,
+        "value": float(F) * L * steps / elapsed / 1e6, "value_steady": float(F) * L / (step_median * 1e-3) / 1e6,
+        "value_sustained": (float(F) * L / (sustained_median * 1e-3) / 1e6) if sustained_median else None,
+        "ms_per_step": step_ms, "ms_per_step_median": step_median, "ms_per_step_series": [round(float(x), 3) for x in step_times[:64]],
+        "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
+        "roofline": {"bound": "hbm", "kernel": "update (ACS + decision writeback)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": upd_bytes_launch, "frames_per_launch": F_launch, "launches_in_flight": NUPD,
+                     "achieved_all_launches_over_wall_clock": upd_bytes * steps / elapsed / 1e9},
+        "roofline_end_to_end": {"bound": "hbm", "achieved": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": (upd_bytes + cb_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "state_updates_per_s": float(F_launch) * S * code.num_states / (upd_ms * 1e-3),
+        "parity": parity, "ber": ber,
+    }
+    rates = issue_rates()
+    if valu_insts and rates:
+        ns = rates["packed16_ns_per_wave_instr_per_simd"]
+        dec._handle.refresh()
+        waves = (-(-F_launch // dec._handle.info.workspace_tile_frames) / float(N_SIMD) * NUPD) if dec.plan == _lib.PLAN_REG else None
+        wkey = "4" if waves is None else str(int(min(4, max(1, -(-waves // 1)))))
+        ach = valu_insts / (upd_ms * 1e-3) / 1e9 * NUPD
+        rec["roofline_valu"] = {"bound": "valu", "kernel": "update", "achieved": ach, "peak": N_SIMD / ns[wkey], "unit": "G wave-instr/s",
+                                "frac": ach / (N_SIMD / ns[wkey]), "peak_spec": N_SIMD * CLOCK_GHZ / 2.0, "frac_of_spec": ach / (N_SIMD * CLOCK_GHZ / 2.0),
+                                "valu_insts_per_launch": valu_insts, "launches_in_flight": NUPD, "update_waves_per_simd": waves,
+                                "peak_source": rates["source"], "insts_source": traffic_src}
+    pipe.close()
+    del pipe, dec, sym, tx, out
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    rec["seconds_spent"] = time.perf_counter() - t_case
+    return rec
 
 
 def dry_run(args, world, rank, affinity):
@@ -471,17 +611,42 @@ def main():
     # local ranks wait for a MARKER that rank 0 writes after the build has RETURNED (the .so exists long before the linker has
     # finished writing it); the marker is keyed by this launch's rendezvous port, so a stale one from another run is never taken
     lib_path = os.path.join(ROOT, "viterbidecodercpp_amd", "libvit_hip.so")
+    # torchrun's defaults (port 29500, run id "none") repeat from run to run: a marker left by an EARLIER launch must never satisfy
+    # this one's wait.  The marker therefore carries rank 0's pid and start time, waiters accept it only while that very process is
+    # alive and younger than the marker, and rank 0 removes it at exit.
     marker = os.path.join("/tmp", f"vit_hip_built.{os.getuid()}.{os.environ.get('MASTER_PORT', '0')}.{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}")
+
+    def proc_start(pid):
+        try:
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[19]     # starttime, in clock ticks since boot
+        except (OSError, IndexError):
+            return None
+
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        if not os.path.exists(lib_path):
+        if world > 1:
+            try:
+                os.unlink(marker)               # a stale one from an earlier run with the same port / run id
+            except OSError:
+                pass
+        if not os.path.exists(lib_path) and not args.dry_run:      # --dry-run rehearses on a CPU-only host: nothing to build there
             import __graft_entry__
             __graft_entry__.build()
         if world > 1:
-            with open(marker, "w") as f:
-                f.write(str(os.getpid()))
-    elif not os.path.exists(lib_path) or world > 1:
+            import atexit
+            tmp = f"{marker}.{os.getpid()}"
+            with open(tmp, "w") as f:
+                f.write(f"{os.getpid()} {proc_start(os.getpid())}")
+            os.rename(tmp, marker)
+            atexit.register(lambda: os.path.exists(marker) and os.unlink(marker))
+    elif (not os.path.exists(lib_path) and not args.dry_run) or world > 1:
         t_wait = time.time()
-        while not os.path.exists(marker):
+        while True:
+            try:
+                pid, start = open(marker).read().split()
+                if proc_start(int(pid)) == start:
+                    break                       # written by a rank 0 that is still running: this launch's
+            except (OSError, ValueError):
+                pass
             if time.time() - t_wait > 1800:
                 sys.exit("bench.py: local rank 0 never finished building libvit_hip.so")
             time.sleep(0.2)
@@ -801,6 +966,30 @@ def main():
         sm = torch.tensor([sustained_median_all or 0.0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(sm, op=dist.ReduceOp.MAX)
         sustained_median_all = float(sm[0].item()) or None
+    # ---- parity of the last timed launch, on EVERY rank: each one checks frames of ITS OWN shard against the scalar reference
+    # (bytes and every decision word); the pass flags and counts are summed over the ranks.  N = 1: 512 frames; N > 1: 64 per rank
+    parity = None
+    if args.parity or not args.no_cpu_baseline or world > 1:
+        from oracle import pyoracle
+        if world > 1:
+            if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+                pyoracle.ensure_built()          # one builder per node; the others wait at the barrier
+            dist.barrier()
+        try:
+            parity = reference_parity(args.code, code, pc, args.decode_type, last_decisions, sym, out, F, L, n=512 if world == 1 else 64)
+        except Exception as e:                   # a rank whose checker fails still enters the all_reduce below -- as a failure
+            parity = {"frames_checked_vs_scalar_reference": 0, "bit_exact": False, "chainback_bytes_bit_exact": False,
+                      "decision_words_bit_exact": False, "error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            pv = torch.tensor([1.0 if parity["bit_exact"] else 0.0, float(parity["frames_checked_vs_scalar_reference"]), 1.0,
+                               1.0 if parity["chainback_bytes_bit_exact"] else 0.0, 1.0 if parity["decision_words_bit_exact"] else 0.0],
+                              dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(pv, op=dist.ReduceOp.SUM)
+            parity = {"ranks_checked": int(pv[2].item()), "ranks_bit_exact": int(pv[0].item()), "frames_checked": int(pv[1].item()),
+                      "frames_checked_vs_scalar_reference": int(pv[1].item()), "frames_per_rank": parity["frames_checked_vs_scalar_reference"],
+                      "checker": parity.get("checker"), "chainback_bytes_bit_exact": int(pv[3].item()) == world,
+                      "decision_words_bit_exact": int(pv[4].item()) == world, "bit_exact": int(pv[0].item()) == world,
+                      "what": "every rank: the first frames of ITS shard of the last timed launch (rank r owns frames [r*F, (r+1)*F) of one global batch)"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -846,6 +1035,7 @@ def main():
                    "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
         "per_gpu_Mbit_s": value / world, "per_rank_Mbit_s": per_rank, "Msym_s": value * code.R,
         "ranks": {"world_size": world, "ranks_in_blob_allreduce": ranks_seen, "backend": args.backend if world > 1 else None,
+                  "collective_library": collective_library(args.backend) if world > 1 else None,
                   "blob_bytes": len(blob), "blob_checksum_identical_on_all_ranks": blob_sum_all == blob_sum * world,
                   "per_rank": per_rank_info},
         "update_ms": upd_ms, "chainback_ms": cb_ms, "update_launches_in_flight": NUPD,
@@ -907,14 +1097,30 @@ def main():
             "shader_clock_mhz_measured_this_run": [clock_cold[0], clock_after[0]],
             "peak_source": rates["source"], "insts_source": traffic_src}
 
-    if world == 1 and (args.parity or not args.no_cpu_baseline):
-        # parity of the last submitted step's results (the workspace that step wrote)
-        result["parity"] = reference_parity(args.code, code, pc, args.decode_type, last_decisions, sym, out, F, L)
+    if parity is not None:
+        result["parity"] = parity
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.code, code, pc, args.decode_type, sym, L, args.cpu_seconds)
         result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         if "single_socket_extrapolated_Mbit_s" in result["cpu_baseline"]:
             result["speedup_vs_single_socket_extrapolated"] = value / result["cpu_baseline"]["single_socket_extrapolated_Mbit_s"]
+    # ---- the other BASELINE configs, driver-timed in the same line (the reference runs its whole matrix in one invocation:
+    # examples/run_benchmark.cpp:168-179).  Only behind the DEFAULT workload at N = 1; the headline's numbers above are complete
+    # before any of this runs, and its buffers are freed first.
+    default_workload = (args.code, args.decode_type, args.frames, args.bits) == BASELINE_CONFIGS[1][:4] and args.plan == "auto"
+    if world == 1 and args.via == "pipeline" and default_workload and not args.no_extra_configs:
+        import gc
+        pipe.close()
+        del pipe, sym, tx, out
+        gc.collect()
+        torch.cuda.empty_cache()
+        extra = []
+        for idx in (2, 3, 4):
+            try:
+                extra.append(run_case(idx, args.steps, args.warmup, local_rank, dev, sustain_seconds=min(1.0, args.sustain_seconds)))
+            except Exception as e:
+                extra.append({"baseline_config": idx, "error": f"{type(e).__name__}: {e}"})
+        result["configs"] = extra
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -72,7 +72,8 @@ extern "C" {
 #define VIT_HIP_PLAN_AUTO 0
 #define VIT_HIP_PLAN_LDS 1  /* state metrics staged in LDS, one wavefront per contiguous state slab, ballot decisions */
 #define VIT_HIP_PLAN_REG 2  /* state metrics resident in VGPRs, frames in pairs, packed 16-bit ACS (K = 2..9, R <= 6).
-                               The stock codes are built in; for other polynomials vit_hip_set_plan(h, PLAN_REG) compiles
+                               The stock codes are built in; other polynomials: precompiled at install time
+                               (vit_hip_precompile: no compiler on the serving host) or vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32
                                metrics updated in place in LDS (K = 10..16, R <= 6, any polynomials; K = 10 at half
@@ -107,8 +108,20 @@ int vit_hip_create(int K, int R, int soft_bytes, int error_bytes, const void* br
                    int device, vit_hip_handle* out);
 int vit_hip_destroy(vit_hip_handle h);
 int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info);
-/* PLAN_AUTO never compiles anything: it resolves to a built-in plan (set VIT_HIP_JIT=1 before vit_hip_create to let it). */
+/* PLAN_AUTO never compiles anything: it resolves to a built-in plan, or to PLAN_REG for a code whose kernels were precompiled at
+ * install time (vit_hip_precompile below) -- set VIT_HIP_JIT=1 before vit_hip_create to let it compile. */
 int vit_hip_set_plan(vit_hip_handle h, int plan);
+/* Install-time instantiation of the register plan for one polynomial set and symbol width (soft_bytes 1 or 2), for hosts that run
+ * WITHOUT a compiler.  In the reference the polynomials are a run-time constructor argument of the branch table
+ * (include/viterbi/viterbi_branch_table.h:34-55) and any set runs at the compiled <K,R>'s full speed; here the register plan's
+ * kernels are specialised per set, so sets outside the eight stock codes are compiled ahead of use: this call writes the code
+ * object into `directory` (NULL: the package cache `<directory of libvit_hip.so>/precompiled`, which vit_hip_create consults for
+ * every code it has no built-in kernels for -- such a code then runs PLAN_REG from vit_hip_create on, PLAN_AUTO included).
+ * Needs hipcc ($VIT_HIP_HIPCC, else /opt/rocm/bin/hipcc) and the kernel sources beside the library, but NO GPU: a build host
+ * without a card can run it (python -m viterbidecodercpp_amd.tools.precompile does, for a list of common sets, from build()).
+ * An object that already exists is kept.  path_out (optional) receives the file's path.  K = 2..9, R <= 6. */
+int vit_hip_precompile(int K, int R, const uint32_t* polynomials, int soft_bytes, const char* directory, char* path_out,
+                       size_t path_capacity);
 /* One line of text about the plan the handle runs and -- where that is PLAN_LDS, the compatibility plan -- whether a faster one
  * exists for this (K, R) and how to get it: no combination the header-level is_valid admits lands on the slow plan silently.
  * Thread-local storage, valid until the thread's next call.  (The reference has no counterpart: its strategies are chosen at

@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 cd /tmp
 STEPS=${PROFILE_STEPS:-20}
 WARM=${PROFILE_WARMUP:-10}      # the card ramps its clocks over the first ~10 launches of a fresh process
-ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --sustain-seconds 0 $*"
+ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra-configs --sustain-seconds 0 $*"
 run() { name=$1; shift; timeout -k 10 600 rocprofv3 "$@" -d "$OUT/$name" --output-format csv -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1; echo "$TAG $name rc=$?"; }
 run trace --kernel-trace --stats
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE

@@ -1,12 +1,13 @@
 """C-ABI behaviour on the GPU box: error codes (no exceptions, no crashes), plan selection, workspace checks, empty and
 degenerate batches, handle reuse across batches of different sizes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 from viterbidecodercpp_amd import COMMON_CODES, BatchDecoder, Code, _lib, synth
-from tests.helpers import check_batch_against_oracle, make_table_config
+from tests.helpers import check_batch_against_oracle, make_table_config, oracle_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -213,7 +214,11 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     agree with the oracle exactly like the stock instantiations."""
     code = Code(f"custom K{K}R{R}", K, R, tuple(G))
     pc, table, config = make_table_config(code, decode_type)
-    assert BatchDecoder(table, config).plan == _lib.PLAN_LDS          # AUTO does not compile anything behind the caller's back
+    # AUTO does not compile anything behind the caller's back, and does not look into the user cache: PLAN_REG only for the sets
+    # that were precompiled into the package at install time (tools/precompile.py: COMMON_SETS)
+    from viterbidecodercpp_amd.tools.precompile import COMMON_SETS
+    in_package = any((K, R, tuple(G)) == (k, r, g) for _, k, r, g in COMMON_SETS)
+    assert BatchDecoder(table, config).plan == (_lib.PLAN_REG if in_package else _lib.PLAN_LDS)
     dec = check_batch_against_oracle(oracle, code, decode_type, 70, 384, 3.0, seed=K * R, plan=_lib.PLAN_REG)
     assert dec.plan == _lib.PLAN_REG
     # the run-time compiled code object's kernel descriptors are readable too (the pipeline's residency rules need them): from
@@ -265,6 +270,71 @@ def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tm
     assert b"hipcc" in msg, msg
     dec._handle.refresh()
     assert dec.plan == _lib.PLAN_LDS                                  # still usable on the LDS plan
+
+
+def test_precompiled_package_cache_serves_plan_reg_without_a_compiler(oracle, monkeypatch, tmp_path):
+    """the reference takes the polynomials at run time (viterbi_branch_table.h:34-55).  The world's most deployed K = 7 pair in its
+    standard orientation (0o171, 0o133) is not a stock code: with NO compiler on the host and an EMPTY user cache, vit_hip_create
+    (PLAN_AUTO) still runs it on the register plan, from the code object build() precompiled into the package cache -- bit-exact,
+    at the stock code's rate (65536 x 8192 through the pipeline: >= 140 Gbit/s)."""
+    import time
+
+    import torch
+    from viterbidecodercpp_amd import DecodePipeline
+
+    monkeypatch.setenv("VIT_HIP_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("VIT_HIP_CACHE_DIR", str(tmp_path))
+    monkeypatch.delenv("VIT_HIP_JIT", raising=False)
+    for K, R, G, decode_type in ((7, 2, (0o171, 0o133), "SOFT16"), (7, 2, (0o171, 0o133), "HARD8"), (5, 2, (0o23, 0o33), "SOFT8"),
+                                 (9, 2, (0o561, 0o753), "SOFT16"), (7, 3, (0o171, 0o165, 0o133), "SOFT8")):
+        code = Code(f"K{K}R{R}", K, R, G)
+        dec = check_batch_against_oracle(oracle, code, decode_type, 70, 384, 2.0, seed=K + R)           # plan=None: PLAN_AUTO
+        assert dec.plan == _lib.PLAN_REG, dec.plan_note
+        assert "package cache" in dec.plan_note and "/precompiled/reg_K" in dec.plan_note, dec.plan_note
+    assert not any(f.endswith(".hsaco") for f in os.listdir(tmp_path))          # nothing was compiled
+    # a set that was NOT precompiled stays on the compatibility plan, and asking for the register plan is a clean error here
+    pc, table, config = make_table_config(Code("custom", 7, 2, (0o147, 0o135)), "SOFT16")
+    assert BatchDecoder(table, config).plan == _lib.PLAN_LDS
+    # rate: the headline batch size
+    code = Code("802.11 K7", 7, 2, (0o171, 0o133))
+    pc, table, config = make_table_config(code, "SOFT16")
+    dec = BatchDecoder(table, config)
+    F, L = 65536, 8192
+    tx, sym = dec.synth(F, L, 3.0, seed=5)
+    out = torch.empty((F, L // 8), dtype=torch.uint8, device="cuda")
+    pipe = DecodePipeline(dec, F, L)
+    for _ in range(4):
+        pipe.submit(sym, out)
+    pipe.sync()
+    t0 = time.perf_counter()
+    for _ in range(12):
+        pipe.submit(sym, out)
+    pipe.sync()
+    gbit = 12 * F * L / (time.perf_counter() - t0) / 1e9
+    ber = float((torch.bitwise_xor(out, tx).to(torch.int32).view(-1) != 0).float().mean())
+    assert ber < 2e-2
+    n = 64
+    want, _, _ = oracle.decode_frames(7, 2, code.G, oracle_cfg("SOFT16", 2), sym[:n].cpu().numpy(), L, threads=8)
+    assert np.array_equal(out[:n].cpu().numpy(), want)
+    print(f"precompiled K7 0o171/0o133 SOFT16 65536 x 8192: {gbit:.1f} Gbit/s")
+    assert gbit >= 140.0, gbit
+
+
+def test_runtime_compile_on_the_box(oracle, monkeypatch, tmp_path):
+    """the compile path itself (every other run-time instantiated set of this suite comes precompiled from tests/_jit_cache): an
+    empty user cache, hipcc on the box, a set nobody precompiled -- vit_hip_set_plan(PLAN_REG) compiles it, the note names the user
+    cache, and a second handle loads the object without compiling."""
+    monkeypatch.setenv("VIT_HIP_CACHE_DIR", str(tmp_path))
+    code = Code("custom K4", 4, 2, (0o13, 0o17))
+    dec = check_batch_against_oracle(oracle, code, "SOFT16", 70, 384, 3.0, seed=4, plan=_lib.PLAN_REG)
+    assert dec.plan == _lib.PLAN_REG and "user cache" in dec.plan_note and str(tmp_path) in dec.plan_note, dec.plan_note
+    objs = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(objs) == 1 and objs[0].startswith("reg_K4R2_11_15_0_0_0_0_s16_gfx950_"), objs
+    st = os.stat(os.path.join(tmp_path, objs[0]))
+    assert (st.st_mode & 0o077) == 0                                            # private to this user
+    monkeypatch.setenv("VIT_HIP_HIPCC", "/nonexistent/hipcc")                   # the cached object needs no compiler
+    pc, table, config = make_table_config(code, "SOFT16")
+    assert BatchDecoder(table, config, plan=_lib.PLAN_REG).plan == _lib.PLAN_REG
 
 
 @pytest.mark.parametrize("code_id,decode_type,plans", [

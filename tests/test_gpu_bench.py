@@ -69,6 +69,13 @@ def test_gpus_2_spawns_two_ranks_on_one_card():
     assert all(x["pinned_to_gpu_local_cpus"] and x["cpus"] >= 1 for x in pr), pr
     assert "cpu_baseline" not in r            # rank 0 at N=1 only
     assert 0 <= r["ber"] < 1e-2
+    # the N > 1 line carries its own correctness evidence: every rank checked frames of ITS shard of the last timed launch against the
+    # scalar reference (bytes and every decision word); flags and counts are summed over the ranks
+    par = r["parity"]
+    assert par["ranks_checked"] == 2 and par["ranks_bit_exact"] == 2 and par["bit_exact"] is True, par
+    assert par["frames_checked"] == 128 and par["frames_per_rank"] == 64 and par["decision_words_bit_exact"] and par["chainback_bytes_bit_exact"], par
+    assert r["ranks"]["backend"] == "gloo" and r["ranks"]["collective_library"]["name"] == "gloo"
+    assert "configs" not in r                 # the other BASELINE configs ride on the default N = 1 line only
 
 
 @pytest.mark.gpu
@@ -102,7 +109,22 @@ def test_headline_line_carries_its_spread_and_both_routes_agree():
     """the default workload (BASELINE configs[1]) through the shipped pipeline API: the per-step times recorded on the device
     bracket their median, the median agrees with the wall-clock figure, and the Python re-implementation of the schedule
     (--via python) lands on the same rate."""
-    a = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"))
+    a = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--parity"))
+    assert a["parity"]["bit_exact"] and a["parity"]["frames_checked_vs_scalar_reference"] == 512
+    # the default workload's line also carries BASELINE configs[2], [3] (one GPU's share) and [4], each timed through the same pipeline
+    # API with its own roofline and parity block (the reference runs its whole matrix in one invocation: run_benchmark.cpp:168-179)
+    cfgs = a["configs"]
+    assert [c["baseline_config"] for c in cfgs] == [2, 3, 4] and not any("error" in c for c in cfgs), cfgs
+    for c, (K, dt, F, nchk) in zip(cfgs, ((9, "u16", 65536, 64), (7, "u8", 32768, 64), (15, "u16", 4096, 8))):
+        assert f"K={K} " in c["config"]["workload"] and c["dtype"] == dt and c["config"]["frames_per_gpu"] == F
+        assert c["parity"]["bit_exact"] and c["parity"]["frames_checked_vs_scalar_reference"] == nchk, c["parity"]
+        assert c["value"] <= c["value_steady"] * 1.02 and c["value_sustained"] > 0.9 * c["value_steady"], c
+        rf = c["roofline"]
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (c["update_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"] and 0 < rf["frac"] < 1
+        assert rf["traffic"] is not None and 0.95 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.15, rf
+        assert 0.5 < c["roofline_valu"]["frac"] < 1.05 and 0 <= c["ber"] < 1e-2, c
+    assert cfgs[1]["update_launches_in_flight"] == 2
+    assert sum(c["seconds_spent"] for c in cfgs) < 90, [c["seconds_spent"] for c in cfgs]
     assert a["config"]["frames_per_gpu"] == 65536 and a["config"]["bits_per_frame"] == 8192 and a["config"]["via"] == "pipeline"
     assert a["ms_per_step_min"] <= a["ms_per_step_median"] <= a["ms_per_step_max"]
     # wall clock over the timed region = the steady step (the median) + one pipeline fill and drain (the first update has no
@@ -115,6 +137,7 @@ def test_headline_line_carries_its_spread_and_both_routes_agree():
     assert rv["peak_spec"] > rv["peak"] and 0 < rv["frac_of_spec"] < rv["frac"] < 1.0, rv
     assert len(a["ms_per_step_series"]) == 20 and abs(sum(a["ms_per_step_series"]) / 20 - a["ms_per_step"]) < 0.05 * a["ms_per_step"]
     b = _json_line(_run("--config", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--via", "python"))
+    assert "configs" not in b
     assert b["config"]["via"] == "python"
     # the Python re-implementation queues the same kernels from the interpreter (a few microseconds later per launch): it may
     # trail the C route by a few per cent, never lead it by much

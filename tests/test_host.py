@@ -153,3 +153,55 @@ def test_kernel_descriptor_reader_on_a_run_time_compiled_code_object(tmp_path):
         assert got[name] == (-(-f("next_free_vgpr") // 8) * 8, f("group_segment_fixed_size"), f("private_segment_fixed_size")), (name, got[name])
     # the finding itself, kept as a regression: static LDS that admits one wave per SIMD pads the allocation past 256 registers
     assert got["padded"][0] >= 264 and got["padded"][1] == 40960 and got["lean"][0] <= 32 and got["lean"][1] == 0, got
+
+
+def test_precompile_writes_a_code_object_without_a_gpu(tmp_path):
+    """vit_hip_precompile (include/vit_hip.h): install-time instantiation of the register plan for a polynomial set -- hipcc only,
+    no GPU call, so it runs on this build host; the object's name carries code, width, target and source hash; an existing object is
+    kept (second call: no compiler needed); what the register plan does not serve is an error code."""
+    import ctypes as C
+    import shutil
+
+    from viterbidecodercpp_amd import _lib
+    from viterbidecodercpp_amd.tools import precompile
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    lib = _lib.load()
+    paths = precompile.precompile([(2, 2, (0o3, 0o1), 2)], str(tmp_path), verbose=False)
+    name = os.path.basename(paths[0])
+    assert name.startswith("reg_K2R2_3_3_0_0_0_0_s16_gfx950_") and name.endswith(".hsaco"), name      # 0o1 -> 0o3: bit 0 and bit K-1 are implied
+    blob = open(paths[0], "rb").read()
+    assert b"vit_jit_update_16" in blob and b"vit_jit_chainback" in blob and b"gfx950" in blob
+    assert sorted(os.listdir(tmp_path)) == [name]                                 # no source, log or temporary left behind
+    os.environ["VIT_HIP_HIPCC"] = "/nonexistent/hipcc"
+    try:
+        assert precompile.precompile([(2, 2, (0o3, 0o1), 2)], str(tmp_path), verbose=False) == paths
+        G = (C.c_uint32 * 6)(0o5, 0o7)
+        assert lib.vit_hip_precompile(3, 2, G, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_RUNTIME and b"hipcc" in lib.vit_hip_last_error()
+    finally:
+        del os.environ["VIT_HIP_HIPCC"]
+    G = (C.c_uint32 * 6)(0o1167, 0o1545)
+    assert lib.vit_hip_precompile(10, 2, G, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_precompile(7, 2, G, 4, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
+    # the package cache build() fills: every common set, both widths, compiled from the CURRENT kernel sources
+    pkg = os.path.join(ROOT, "viterbidecodercpp_amd", "precompiled")
+    have = set(os.listdir(pkg)) if os.path.isdir(pkg) else set()
+    suffix = name.rsplit("_", 1)[1]
+    for _, K, R, Gs in precompile.COMMON_SETS:
+        for w in (8, 16):
+            g = [x | 1 | (1 << (K - 1)) for x in Gs] + [0] * (6 - R)
+            want = f"reg_K{K}R{R}_" + "_".join(str(x) for x in g) + f"_s{w}_gfx950_{suffix}"
+            assert want in have, f"{want} missing from {pkg}: run build()"
+
+
+def test_traffic_json_follows_from_its_sources():
+    """profiles/traffic.json (bench.py's roofline.traffic and roofline_valu instruction counts) is derived data: every entry must be
+    what scripts/make_traffic.py computes from the rocprofv3 summary its `source` names."""
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_traffic.py"), "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    for key, e in json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).items():
+        assert os.path.exists(os.path.join(ROOT, e["source"])), (key, e["source"])

@@ -8,7 +8,8 @@
 //                     created 0700 and used only if it belongs to this user and nobody else can write to it -- a code
 //                     object found there is loaded into the caller's GPU context, so it must not be plantable by others
 //   compiler        : $VIT_HIP_HIPCC, else /opt/rocm/bin/hipcc; started with posix_spawn and an argv array (a fresh child
-//                     process, no shell); its version string and the target arch are part of the cache key
+//                     process, no shell).  Needed only to COMPILE: a code object that is already in the package cache
+//                     (precompiled at install time, see below) or in the user cache loads on a host without any compiler
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -136,80 +137,120 @@ inline std::map<std::string, RegJitModule*>& modules() { static std::map<std::st
 
 }  // namespace jit_detail
 
-// returns nullptr and fills `err` on failure.  The module belongs to the current device.
-// one code object per (code, symbol width): a decoder handle has ONE width, and the update / resume kernels of the other one are
-// half of the compile time (1 - 4 minutes for the K = 8, 9 codes)
-inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shift, int device, std::string& err) {
+// The code objects have two homes:
+//   * the PACKAGE cache `<directory of libvit_hip.so>/precompiled/` -- written at install / build time by
+//     `python -m viterbidecodercpp_amd.tools.precompile` (vit_hip_precompile), read-only at run time and as trustworthy as the
+//     library beside it.  vit_hip_create consults it for every code outside the ahead-of-time table: a code found there runs
+//     PLAN_REG from the first call on a host that has no compiler at all;
+//   * the USER cache (cache_dir()): filled by run-time compilation (vit_hip_set_plan(PLAN_REG) / VIT_HIP_JIT=1), consulted only then.
+// A file's name carries the code, the symbol width, the target and a hash of the kernel sources it was compiled from (NOT the
+// compiler's version: any hipcc's gfx950 code object of these sources is the same kernel), so a stale object is never found.
+inline std::string package_cache_dir() { return jit_detail::this_library_dir() + "/precompiled"; }
+
+// file name (without directory) of the code object of one (code, symbol width); empty + err when the kernel sources are not
+// beside the library
+inline std::string reg_jit_object_name(int K, int R, const uint32_t* G, int shift, std::string& err) {
     using namespace jit_detail;
-    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 2..9 with R <= 6"; return nullptr; }
+    const std::string src_dir = this_library_dir() + "/csrc";
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a_file(src_dir + "/kernels_reg.hpp", h);
+    h = fnv1a_file(src_dir + "/common.hpp", h);
+    if (h == 1469598103934665603ull) { err = "kernel sources not found next to the library (" + src_dir + ")"; return std::string(); }
+    h = fnv1a_file(src_dir + "/kernel_desc.hpp", h);
+    std::ostringstream key;
+    key << "reg_K" << K << "R" << R;
+    for (int i = 0; i < 6; ++i) key << "_" << (i < R ? G[i] : 0u);
+    key << (shift ? "_s8" : "_s16") << "_gfx950_" << std::hex << h << ".hsaco";
+    return key.str();
+}
+
+// Compile the four (five) kernels of one code and symbol width into `hsaco` (atomic rename; the log stays beside it on failure).
+// No GPU call: this also runs on a build host without a card.
+inline bool reg_jit_compile(int K, int R, const uint32_t* G, int shift, const std::string& hsaco, std::string& err) {
+    using namespace jit_detail;
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 2..9 with R <= 6"; return false; }
     const int lane_bits = K >= 7 ? 2 : 0;
     const std::string src_dir = this_library_dir() + "/csrc";
     const char* cc_env = getenv("VIT_HIP_HIPCC");
     const std::string hipcc = cc_env && *cc_env ? cc_env : "/opt/rocm/bin/hipcc";
-    const std::string arch = "gfx950";
-    std::lock_guard<std::mutex> lock(mutex());
-    // compiler identity: once per process
-    static std::string cc_version;
-    if (cc_version.empty()) {
-        if (run_child({hipcc, "--version"}, "", &cc_version) != 0 || cc_version.empty()) {
-            cc_version.clear();
-            err = "cannot run " + hipcc + " --version";
-            return nullptr;
-        }
+    if (access(hipcc.c_str(), X_OK) != 0) { err = "cannot run " + hipcc + " (hipcc is needed to compile a register-plan instantiation; set VIT_HIP_HIPCC, or precompile on a build host: python -m viterbidecodercpp_amd.tools.precompile)"; return false; }
+    const std::string base = hsaco.substr(0, hsaco.size() > 6 ? hsaco.size() - 6 : hsaco.size());   // strip ".hsaco"
+    const std::string src = base + "." + std::to_string((long)getpid()) + ".hip";
+    {
+        std::ofstream f(src);
+        f << "#define VIT_REG_JIT_TU 1\n";
+        if (K == 9 || (K == 7 && R == 3)) f << "#define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))\n";   // kernels_reg.hpp, reg_update_kernel
+        f << "#include \"" << src_dir << "/kernels_reg.hpp\"\n"
+          << "using SP = vit::RegSpec<" << K << ", " << R;
+        for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
+        f << ", " << lane_bits << ", " << (4 < R ? G[4] : 0u) << "u, " << (5 < R ? G[5] : 0u) << "u>;\n"
+          << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_" << (shift ? 8 : 16)
+          << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, " << (shift ? 8 : 0) << ", false>(a); }\n"
+          << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_" << (shift ? 8 : 16) << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, "
+          << (shift ? 8 : 0) << ", true>(a); }\n"
+          << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_min_waves<SP>()) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
+          << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
+        if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_alt(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";
+        if (!f) { err = "cannot write " + src; return false; }
     }
-    uint64_t h = 1469598103934665603ull;
-    h = fnv1a_file(src_dir + "/kernels_reg.hpp", h);
-    h = fnv1a_file(src_dir + "/common.hpp", h);
-    if (h == 1469598103934665603ull) { err = "kernel sources not found next to the library (" + src_dir + ")"; return nullptr; }
-    h = fnv1a_str(cc_version, h);
-    h = fnv1a_str(arch, h);
-    std::ostringstream key;
-    key << "reg_K" << K << "R" << R;
-    for (int i = 0; i < 6; ++i) key << "_" << (i < R ? G[i] : 0u);
-    key << (shift ? "_s8" : "_s16") << "_" << arch << "_" << std::hex << h;
-    const std::string mkey = key.str() + "@" + std::to_string(device);
-    auto it = modules().find(mkey);
-    if (it != modules().end()) return it->second;
+    const std::string tmp = hsaco + "." + std::to_string((long)getpid()) + ".tmp";
+    const int rc = run_child({hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--genco", "-o", tmp, src}, base + ".log", nullptr);
+    if (rc != 0 || access(tmp.c_str(), R_OK) != 0) {
+        (void)unlink(tmp.c_str());
+        err = "hipcc failed for the run-time PLAN_REG instantiation (see " + base + ".log)";
+        return false;
+    }
+    (void)chmod(tmp.c_str(), 0644);
+    if (rename(tmp.c_str(), hsaco.c_str()) != 0) { (void)unlink(tmp.c_str()); err = "cannot move the code object to " + hsaco; return false; }
+    (void)unlink(src.c_str());
+    (void)unlink((base + ".log").c_str());
+    return true;
+}
 
-    const std::string dir = cache_dir();
-    if (dir.empty()) { err = "no private cache directory for run-time compiled kernels (set VIT_HIP_CACHE_DIR to a directory only you can write)"; return nullptr; }
-    const std::string base = dir + "/" + key.str();
-    const std::string hsaco = base + ".hsaco";
-    if (!private_to_user(hsaco, false)) {
-        (void)unlink(hsaco.c_str());                 // not ours or writable by others: never load it
-        const std::string src = base + "." + std::to_string((long)getpid()) + ".hip";
-        {
-            std::ofstream f(src);
-            f << "#define VIT_REG_JIT_TU 1\n";
-            if (K == 9 || (K == 7 && R == 3)) f << "#define VIT_REG_UPDATE_VGPR_CAP __attribute__((amdgpu_num_vgpr(120)))\n";   // kernels_reg.hpp, reg_update_kernel
-            f << "#include \"" << src_dir << "/kernels_reg.hpp\"\n"
-              << "using SP = vit::RegSpec<" << K << ", " << R;
-            for (int i = 0; i < 4; ++i) f << ", " << (i < R ? G[i] : 0u) << "u";
-            f << ", " << lane_bits << ", " << (4 < R ? G[4] : 0u) << "u, " << (5 < R ? G[5] : 0u) << "u>;\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_update_min_waves<SP>()) VIT_REG_UPDATE_VGPR_CAP vit_jit_update_" << (shift ? 8 : 16)
-              << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, " << (shift ? 8 : 0) << ", false>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, 1) vit_jit_resume_" << (shift ? 8 : 16) << "(vit::RegUpdateArgs a) { vit::reg_update_body<SP, "
-              << (shift ? 8 : 0) << ", true>(a); }\n"
-              << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_min_waves<SP>()) vit_jit_chainback(vit::RegChainbackArgs a) { if (a.wave_priority) __builtin_amdgcn_s_setprio(3); vit::reg_chainback_body<SP>(a); }\n"
-              << "extern \"C\" __global__ void vit_jit_export(vit::RegExportArgs a) { vit::reg_export_body<SP>(a); }\n";
-            if (K == 9 || K == 7) f << "extern \"C\" __global__ void __launch_bounds__(64, vit::reg_chainback_alt_min_waves<SP>()) vit_jit_chainback_alt(vit::RegChainbackArgs a) { vit::reg_chainback_alt_body<SP>(a); }\n";
+// returns nullptr and fills `err` on failure.  The module belongs to the current device.
+// one code object per (code, symbol width): a decoder handle has ONE width, and the update / resume kernels of the other one are
+// half of the compile time (1 - 4 minutes for the K = 8, 9 codes)
+// `package_only`: look in the package cache and nowhere else, compile nothing (what vit_hip_create does for PLAN_AUTO).
+// `origin` (optional) receives the path of the code object the module was loaded from.
+inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shift, int device, bool package_only, std::string& err,
+                                       std::string* origin = nullptr) {
+    using namespace jit_detail;
+    if (!reg_jit_supported(K, R)) { err = "PLAN_REG run-time instantiation serves K = 2..9 with R <= 6"; return nullptr; }
+    const int lane_bits = K >= 7 ? 2 : 0;
+    const std::string name = reg_jit_object_name(K, R, G, shift, err);
+    if (name.empty()) return nullptr;
+    std::lock_guard<std::mutex> lock(mutex());
+    static std::map<std::string, std::string> origins;
+    const std::string mkey = name + "@" + std::to_string(device);
+    std::string hsaco = package_cache_dir() + "/" + name;
+    auto it = modules().find(mkey);
+    // a module this process loaded from the USER cache does not make the code "installed": package_only keeps ignoring it
+    if (it != modules().end() && (!package_only || origins[mkey] == hsaco)) {
+        if (origin) *origin = origins[mkey];
+        return it->second;
+    }
+    if (it != modules().end()) { err = "no precompiled code object for this code in " + package_cache_dir(); return nullptr; }
+    struct stat st;
+    const bool in_package = stat(hsaco.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+    if (!in_package) {
+        if (package_only) { err = "no precompiled code object for this code in " + package_cache_dir(); return nullptr; }
+        const std::string dir = cache_dir();
+        if (dir.empty()) { err = "no private cache directory for run-time compiled kernels (set VIT_HIP_CACHE_DIR to a directory only you can write)"; return nullptr; }
+        hsaco = dir + "/" + name;
+        if (!private_to_user(hsaco, false)) {
+            (void)unlink(hsaco.c_str());                 // not ours or writable by others: never load it
+            if (!reg_jit_compile(K, R, G, shift, hsaco, err)) return nullptr;
+            (void)chmod(hsaco.c_str(), 0600);
         }
-        const std::string tmp = hsaco + "." + std::to_string((long)getpid()) + ".tmp";
-        const int rc = run_child({hipcc, "-O3", "-std=c++17", "--offload-arch=" + arch, "--genco", "-o", tmp, src}, base + ".log", nullptr);
-        if (rc != 0 || access(tmp.c_str(), R_OK) != 0) {
-            err = "hipcc failed for the run-time PLAN_REG instantiation (see " + base + ".log)";
-            return nullptr;
-        }
-        (void)chmod(tmp.c_str(), 0600);
-        (void)rename(tmp.c_str(), hsaco.c_str());
-        (void)unlink(src.c_str());
+        if (!private_to_user(hsaco, false)) { err = "could not load " + hsaco; return nullptr; }
     }
     RegJitModule* m = new RegJitModule();
-    if (!private_to_user(hsaco, false) || hipModuleLoad(&m->module, hsaco.c_str()) != hipSuccess ||
+    if (hipModuleLoad(&m->module, hsaco.c_str()) != hipSuccess ||
         hipModuleGetFunction(&m->update[shift ? 1 : 0], m->module, shift ? "vit_jit_update_8" : "vit_jit_update_16") != hipSuccess ||
         hipModuleGetFunction(&m->resume[shift ? 1 : 0], m->module, shift ? "vit_jit_resume_8" : "vit_jit_resume_16") != hipSuccess ||
         hipModuleGetFunction(&m->chainback, m->module, "vit_jit_chainback") != hipSuccess ||
         hipModuleGetFunction(&m->export_, m->module, "vit_jit_export") != hipSuccess) {
+        (void)hipGetLastError();
         err = "could not load " + hsaco;
         delete m;
         return nullptr;
@@ -218,6 +259,8 @@ inline const RegJitModule* reg_jit_get(int K, int R, const uint32_t* G, int shif
     (void)kd::parse_file(hsaco, m->kernels);           // an unreadable table only makes the pipeline pick its conservative schedule
     if ((K == 9 || K == 7) && hipModuleGetFunction(&m->chainback_alt, m->module, "vit_jit_chainback_alt") != hipSuccess) m->chainback_alt = nullptr;
     modules()[mkey] = m;
+    origins[mkey] = hsaco;
+    if (origin) *origin = hsaco;
     return m;
 }
 

@@ -77,6 +77,7 @@ struct vit_hip_decoder {
     vit::RegCode reg_code{};        // PLAN_REG description (valid when reg_ok)
     bool reg_ok = false;
     bool lds2_ok = false;
+    std::string reg_origin;         // path of the code object a run-time / install-time compiled PLAN_REG was loaded from
     // host-route scratch
     hipStream_t stream = nullptr;
     void* d_scratch = nullptr;
@@ -169,13 +170,14 @@ int lds_chainback(vit_hip_handle h, const uint64_t* d_decisions, size_t frames, 
 }
 
 // run-time compiled PLAN_REG for polynomials outside the ahead-of-time table (reg_jit.hpp)
-bool try_reg_jit(vit_hip_handle h) {
+// package_only: load an install-time precompiled code object if the package cache holds one; compile nothing
+bool try_reg_jit(vit_hip_handle h, bool package_only) {
     if (h->reg_ok) return true;
     if (!h->linear || !vit::reg_jit_supported(h->K, h->R)) return false;
     std::string err;
-    const vit::RegJitModule* m = vit::reg_jit_get(h->K, h->R, h->G, h->shift, h->device, err);
+    const vit::RegJitModule* m = vit::reg_jit_get(h->K, h->R, h->G, h->shift, h->device, package_only, err, &h->reg_origin);
     if (!m) {
-        g_last_error = err;
+        if (!package_only) g_last_error = err;
         return false;
     }
     h->reg_code.id = -1;
@@ -366,8 +368,9 @@ static int vit_hip_create_impl(int K, int R, int soft_bytes, int error_bytes, co
     }
     h->reg_ok = h->linear && vit::reg_code_supported(K, R) && vit::reg_code_init(&h->reg_code, K, R, h->G, h->cfg);
     if (!h->reg_ok && h->linear && vit::reg_jit_supported(K, R)) {
+        // a code object precompiled at install time (package cache, reg_jit.hpp) is as good as a built-in one: no compiler runs
         const char* e = getenv("VIT_HIP_JIT");
-        if (e && *e == '1') (void)try_reg_jit(h);   // opt-in at create time; vit_hip_set_plan(PLAN_REG) always tries
+        if (!try_reg_jit(h, true) && e && *e == '1') (void)try_reg_jit(h, false);   // compiling: opt-in at create time; vit_hip_set_plan(PLAN_REG) always tries
     }
     h->lds2_ok = h->linear && vit::lds2_supported(K, R);   // the group-B tables rely on the code being linear
     h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
@@ -395,11 +398,16 @@ const char* vit_hip_plan_note(vit_hip_handle h) {
              : h->plan == VIT_HIP_PLAN_LDS2 ? "PLAN_LDS2 (frame pair per workgroup, four trellis steps per barrier)"
                                             : "PLAN_LDS, the COMPATIBILITY plan (one frame per workgroup: ~20x slower per state update than the other plans)");
     note = head;
+    if (h->plan == VIT_HIP_PLAN_REG && h->reg_code.jit) {
+        const bool pkg = h->reg_origin.compare(0, vit::package_cache_dir().size(), vit::package_cache_dir()) == 0;
+        note += std::string(pkg ? "; kernels precompiled at install time, loaded from the package cache " : "; kernels compiled at run time, loaded from the user cache ") + h->reg_origin;
+    }
     if (h->plan == VIT_HIP_PLAN_LDS) {
         if (h->reg_ok || (h->linear && vit::reg_jit_supported(h->K, h->R)))
             note += h->reg_ok ? "; the register plan is available: vit_hip_set_plan(h, VIT_HIP_PLAN_REG)"
                               : "; a register-plan instantiation for these polynomials can be compiled at run time: vit_hip_set_plan(h, VIT_HIP_PLAN_REG) "
-                                "(hipcc, 30-60 s once, cached on disk), or VIT_HIP_JIT=1 before vit_hip_create";
+                                "(hipcc, 30-60 s once, cached on disk), or VIT_HIP_JIT=1 before vit_hip_create; or at install time, for hosts without a "
+                                "compiler: python -m viterbidecodercpp_amd.tools.precompile K R G... (vit_hip_precompile)";
         else if (h->lds2_ok)
             note += "; PLAN_LDS2 is available: vit_hip_set_plan(h, VIT_HIP_PLAN_LDS2)";
         else if (!h->linear)
@@ -428,7 +436,7 @@ static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
     if (plan == VIT_HIP_PLAN_REG && !h->reg_ok) {
         DeviceGuard guard(h->device);
         g_last_error.clear();
-        if (!guard.ok || !try_reg_jit(h))
+        if (!guard.ok || !try_reg_jit(h, false))
             return fail(VIT_HIP_ERR_UNSUPPORTED, "PLAN_REG not available for this code: " +
                         (g_last_error.empty() ? std::string("K must be 2..9 and R <= 6, linear branch table") : g_last_error));
     }
@@ -939,8 +947,9 @@ int vit_hip_pipeline_get_schedule_v2(vit_hip_pipeline_t p, vit_hip_pipeline_sche
 }
 
 int vit_hip_pipeline_get_schedule(vit_hip_pipeline_t p, vit_hip_pipeline_schedule* s) {
-    // the struct as binaries built against the first header know it: nothing past sub_batch_frames is written
-    return vit_hip_pipeline_get_schedule_v2(p, s, offsetof(vit_hip_pipeline_schedule, sub_batch_frames) + sizeof(size_t));
+    // the struct as binaries built against the header that introduced this symbol know it: it already ended in
+    // chainback_small_kernel + reserved and this entry point filled them.  Fields added later are reached through _v2 only.
+    return vit_hip_pipeline_get_schedule_v2(p, s, offsetof(vit_hip_pipeline_schedule, reserved) + sizeof(int32_t));
 }
 
 int vit_hip_pipeline_wait_event(vit_hip_pipeline_t p, void* event) {
@@ -1343,9 +1352,10 @@ int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L
         ca.L = (uint32_t)L;
         ca.K = h->K;
         if (L > 0xFFFFFFF0ull) return fail(VIT_HIP_ERR_INVALID_ARG, "L too large");
-        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(vit::one_chainback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)vit::one_chainback_lds_bytes()) == hipSuccess;
-        if (!attr_ok) return fail(VIT_HIP_ERR_RUNTIME, "hipFuncSetAttribute(one_chainback_kernel) failed");
+        // per launch, like every other > 64 KiB launcher of the library: the attribute belongs to the CURRENT device's function object
+        // (a process-wide `static` would opt in only the device of the first caller: a decoder on device 1..7 launched without it)
+        VIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vit::one_chainback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)vit::one_chainback_lds_bytes()));
         hipLaunchKernelGGL(vit::one_chainback_kernel, dim3(1), dim3(64), vit::one_chainback_lds_bytes(), h->stream, ca);
         VIT_HIP_CHECK(hipGetLastError());
     } else {
@@ -1389,6 +1399,32 @@ int vit_hip_create_from_blob(const void* blob, size_t blob_bytes, int device, vi
 
 int vit_hip_set_plan(vit_hip_handle h, int plan) {
     VIT_HIP_NOTHROW(return vit_hip_set_plan_impl(h, plan));
+}
+
+static int vit_hip_precompile_impl(int K, int R, const uint32_t* polynomials, int soft_bytes, const char* directory, char* path_out,
+                                   size_t path_capacity) {
+    if (!polynomials) return fail(VIT_HIP_ERR_INVALID_ARG, "polynomials is NULL");
+    if (soft_bytes != 1 && soft_bytes != 2) return fail(VIT_HIP_ERR_UNSUPPORTED, "soft_bytes must be 1 or 2");
+    if (!vit::reg_jit_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "the register plan serves K = 2..9 with R <= 6");
+    // the same normal form vit_hip_create recovers from a branch table: bit 0 and bit K-1 of every polynomial set
+    uint32_t G[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < R; ++i) G[i] = (polynomials[i] & ((1u << K) - 1u)) | 1u | (1u << (K - 1));
+    std::string err;
+    const int shift = soft_bytes == 1 ? 8 : 0;
+    const std::string name = vit::reg_jit_object_name(K, R, G, shift, err);
+    if (name.empty()) return fail(VIT_HIP_ERR_RUNTIME, err);
+    const std::string dir = directory && *directory ? std::string(directory) : vit::package_cache_dir();
+    (void)mkdir(dir.c_str(), 0755);
+    const std::string path = dir + "/" + name;
+    struct stat st;
+    if (!(stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) && !vit::reg_jit_compile(K, R, G, shift, path, err))
+        return fail(VIT_HIP_ERR_RUNTIME, err);
+    if (path_out && path_capacity) snprintf(path_out, path_capacity, "%s", path.c_str());
+    return VIT_HIP_OK;
+}
+
+int vit_hip_precompile(int K, int R, const uint32_t* polynomials, int soft_bytes, const char* directory, char* path_out, size_t path_capacity) {
+    VIT_HIP_NOTHROW(return vit_hip_precompile_impl(K, R, polynomials, soft_bytes, directory, path_out, path_capacity));
 }
 
 int vit_hip_shader_clock_mhz(int device, double* mhz_out, double* cycles_per_pk_instr_out) {
