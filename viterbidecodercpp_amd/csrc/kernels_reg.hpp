@@ -1055,7 +1055,13 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                     } else {
                         any = __builtin_amdgcn_ballot_w64(pk_max_s(m[0], TLANE) != TCMP) != 0;
                     }
-                    if (__builtin_expect(any, 0)) {   // rare: the body goes out of line, the hot path falls through
+                    if constexpr (NREG >= 64) {
+                    // K = 9 (64 metric registers, 232 of the 240 the cap leaves): round 5's body, kept as it was.  The LDS-free body
+                    // below and its folded subtraction take 40 % of this body's instructions away, and the 8-bit soft rate did rise
+                    // by 1.6 % -- but hipcc then schedules the HOT path of this register-bound kernel 1 - 3 % slower for every decode
+                    // type (same-box A/B, 65536 x 8192: SOFT16 10.96 -> 11.02 - 11.12 ms without the fold, 11.25 - 11.32 with it;
+                    // HARD8 11.30 -> 11.42; SOFT8 12.40 -> 12.20), and two of the reference's three decode types hardly ever take the body
+                    if (__builtin_expect(any, 0)) {
                         const u32 maskq = (SP::LANE_BITS == 0 || lane < 16) ? BIAS2 : 0u;              // formed here, not carried through the hot path
                         const u32 need2 = (pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE) & maskq;   // sign bits: frame A / frame B
                         const u32 nq = SP::LANE_BITS ? (u32)__shfl((int)need2, (int)g) : need2;
@@ -1073,6 +1079,74 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                             constexpr int r = decltype(rc)::value;
                             m[r] = pk_sub(m[r], sub);
                         });
+                        rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
+                        rsB += (uint64_t)((sub >> 16) >> SHIFT);
+                    }
+                    } else
+                    if (__builtin_expect(any, 0)) {   // rare: the body goes out of line, the hot path falls through
+                        u32 mn = m[0];
+                        static_for<NREG - 1>([&](auto rc) __attribute__((always_inline)) {
+                            mn = pk_min_s(mn, m[decltype(rc)::value + 1]);
+                        });
+                        u32 sub;
+                        if constexpr (SP::LANE_BITS) {
+                            // "rare" is every second to fifth step with the reference's 8-bit soft configuration (a frame renormalises
+                            // every 50 - 150 steps, a wave holds 32): the body stays off the LDS.  Round 5 fetched the tripped-half mask
+                            // of lane group 0 and the partial minima of the other three groups with three ds_bpermute, two of them
+                            // awaited back to back (SOFT8 5 - 15 % behind SOFT16 in every code).  Now:
+                            //  * which halves tripped: two 16-bit compares on state 0's register into scalar lane masks; the sixteen
+                            //    bits of lane group 0 are spread over the other three groups on the SCALAR unit (shifts and ors that
+                            //    issue beside the vector instructions) and come back as v_cndmask selectors;
+                            //  * the minimum over the four lane groups: the two swap instructions the butterflies use -- rows (1, 0) and
+                            //    (3, 2) exchanged, then the wave's halves -- with a packed minimum behind each.
+                            const int16_t thr = (int16_t)(uint16_t)(THRM1B2 & 0xFFFFu);
+                            uint64_t tA = __builtin_amdgcn_ballot_w64((int16_t)(uint16_t)(m[0] & 0xFFFFu) > thr);
+                            uint64_t tB = __builtin_amdgcn_ballot_w64((int16_t)(uint16_t)(m[0] >> 16) > thr);
+                            if (a.cfg.threshold == 0) tA = tB = 0xFFFFull;          // "always" (scalar.h:48: metric >= 0)
+                            tA &= 0xFFFFull; tB &= 0xFFFFull;                       // lane group 0 holds state 0
+                            tA |= tA << 16; tA |= tA << 32;
+                            tB |= tB << 16; tB |= tB << 32;
+                            auto s16 = __builtin_amdgcn_permlane16_swap(mn, mn, false, false);
+                            mn = pk_min_s(s16[0], s16[1]);
+                            auto s32 = __builtin_amdgcn_permlane32_swap(mn, mn, false, false);
+                            mn = pk_min_s(s32[0], s32[1]);
+                            const u32 unb = mn ^ BIAS2;           // the true (unbiased) minimum of both frames
+                            u32 sa, sb;
+                            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sa) : "v"(unb), "s"(tA));
+                            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(sb) : "v"(unb), "s"(tB));
+                            sub = (sa & 0x0000FFFFu) | (sb & 0xFFFF0000u);
+                        } else {
+                            const u32 need2 = pk_sub_sat_s_uniform(THRM1B2, m[0]) | FORCE;   // sign bits: frame A / frame B
+                            const u32 msk = ((need2 & 0x8000u) ? 0x0000FFFFu : 0u) | ((need2 & 0x80000000u) ? 0xFFFF0000u : 0u);
+                            sub = (mn ^ BIAS2) & msk;             // the true (unbiased) minimum of each frame that renormalises
+                        }
+                        // Where the step's branch metrics are fewer than the state metrics (rate 1/2 at K = 5, 7, 8, 9: 8 registers
+                        // against 16 - 64) the subtraction goes into the NEXT step's branch metrics, which the look-ahead has already
+                        // put into registers: (m - c) + e == m + (e - c) in the wrapping arithmetic every candidate is formed in, so
+                        // the next step's candidates, decisions and minima are bit for bit those of renormalised metrics -- and are
+                        // themselves the renormalised values the steps behind it start from.  The last step of a call has no next
+                        // step: there the metrics themselves are corrected (they are the call's result).
+#ifndef VIT_REG_FOLD
+#define VIT_REG_FOLD 1
+#endif
+                        constexpr bool FOLD = VIT_REG_FOLD && SP::LANE_BITS != 0 && !BMCHUNK && !SPLIT && 2 * NP < NREG;
+                        bool folded = false;
+                        if constexpr (FOLD) {
+                            if ((!GUARDED && u + 1 < U) || t0 + (u32)u + 1u < a.t_end) {
+                                static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+                                    constexpr int pp = decltype(pc)::value;
+                                    E[(u + 1) & 1][pp] = pk_sub(E[(u + 1) & 1][pp], sub);
+                                    EB[(u + 1) & 1][pp] = pk_sub(EB[(u + 1) & 1][pp], sub);
+                                });
+                                folded = true;
+                            }
+                        }
+                        if (!folded) {
+                            static_for<NREG>([&](auto rc) __attribute__((always_inline)) {
+                                constexpr int r = decltype(rc)::value;
+                                m[r] = pk_sub(m[r], sub);
+                            });
+                        }
                         rsA += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
                         rsB += (uint64_t)((sub >> 16) >> SHIFT);
                     }
