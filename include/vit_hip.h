@@ -374,6 +374,26 @@ int vit_hip_update_host(vit_hip_handle h, void* metrics_inout, const void* symbo
 /* chainback() on host-resident rows: decisions [L+K-1][W].  Synchronous. */
 int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L, size_t end_state, uint8_t* bytes_out);
 
+/* ---- the FRAME route of the header-level drop-in: update() and the chainback() behind it in ONE launch ---------------------------
+ * vit_hip_update_host / vit_hip_chainback_host above keep the reference's division of labour -- every call hands the decision rows
+ * back to the host and takes them in again (core.h:214-236 reads m_decisions on the host) -- which for one frame means two launches,
+ * two synchronisations and four staging copies around 0.3 ms of trellis.  The lazy pair leaves the rows where they were made:
+ *   vit_hip_update_host_lazy    runs n_steps steps like vit_hip_update_host, but stores their decision rows as rows [first_row,
+ *       first_row + n_steps) of the handle's DEVICE row store instead of returning them (the store keeps earlier rows; a handle has
+ *       one frame's rows, as a ViterbiDecoder_Core has one m_decisions).  K <= 7: symbols are read straight from pinned host-mapped
+ *       memory, metrics / renormalisation sum come back through it, and the host polls a completion word instead of synchronising
+ *       the stream.  When the call COMPLETES a frame of `speculate_bits` decoded bits (first_row + n_steps == speculate_bits + K-1;
+ *       0 = never) the same launch also chains back those bits from `speculate_end_state` and keeps the bytes;
+ *   vit_hip_chainback_host_lazy chainback(L, end_state) over the device row store: the bytes kept by the completing update if it was
+ *       asked for exactly this (L, end_state) and no other lazy update ran since -- no GPU work at all -- else one kernel;
+ *   vit_hip_fetch_decisions_host  copies rows of the device row store to the host (what reading m_decisions[row] triggers).
+ * The caller tracks which rows are authoritative where (include/viterbi_hip/viterbi_decoder_core.h does): rows written by
+ * vit_hip_update_host_lazy live on the device until fetched; rows the caller changed on the host make it use the eager pair again. */
+int vit_hip_update_host_lazy(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps, size_t first_row,
+                             size_t speculate_bits, size_t speculate_end_state, uint64_t* renorm_sum_out);
+int vit_hip_chainback_host_lazy(vit_hip_handle h, size_t L, size_t end_state, uint8_t* bytes_out);
+int vit_hip_fetch_decisions_host(vit_hip_handle h, size_t first_row, size_t n_rows, uint64_t* decisions_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,16 +64,18 @@ public:
     static constexpr size_t NUMSTATES = size_t(1) << (K - 1);
     static constexpr size_t TOTAL_BITS_PER_BLOCK = sizeof(format_t) * 8;
     static constexpr size_t TOTAL_BLOCKS = (NUMSTATES / TOTAL_BITS_PER_BLOCK) ? (NUMSTATES / TOTAL_BITS_PER_BLOCK) : 1;
-    void resize(size_t rows) { m_hook(); m_words.resize(rows * TOTAL_BLOCKS); m_rows = rows; }
+    void resize(size_t rows) { m_write_hook(); m_words.resize(rows * TOTAL_BLOCKS); m_rows = rows; }
     size_t size() const { return m_rows; }
-    format_t* operator[](size_t row) { m_hook(); return m_words.data() + row * TOTAL_BLOCKS; }
+    // a mutable row may be written through: the host copy becomes the only authority (m_write_hook); a const row is only brought up to date
+    format_t* operator[](size_t row) { m_write_hook(); return m_words.data() + row * TOTAL_BLOCKS; }
     const format_t* operator[](size_t row) const { m_hook(); return m_words.data() + row * TOTAL_BLOCKS; }
     format_t* raw_row(size_t row) { return m_words.data() + row * TOTAL_BLOCKS; }   // no flush: the decoder's own accesses
-    void set_flush_hook(viterbi_hip_detail::FlushHook h) { m_hook = h; }
+    void set_flush_hook(viterbi_hip_detail::FlushHook h) { m_hook = h; if (!m_write_hook.fn) m_write_hook = h; }
+    void set_write_hook(viterbi_hip_detail::FlushHook h) { m_write_hook = h; }
 private:
     std::vector<format_t> m_words;
     size_t m_rows = 0;
-    viterbi_hip_detail::FlushHook m_hook;
+    viterbi_hip_detail::FlushHook m_hook, m_write_hook;
 };
 
 template <size_t constraint_length, size_t code_rate, typename error_t, typename soft_t>
@@ -96,9 +98,7 @@ public:
             vit_hip_create(int(K), int(R), int(sizeof(soft_t)), int(sizeof(error_t)), branch_table.data(), &m_config, device,
                            &m_hip),
             "vit_hip_create");
-        const viterbi_hip_detail::FlushHook hook{&ViterbiDecoder_Core::flush_hook, this};
-        m_metrics.set_flush_hook(hook);
-        m_decisions.set_flush_hook(hook);
+        install_hooks();
         reset();
         set_traceback_length(0);
     }
@@ -108,6 +108,7 @@ public:
     // history, cursor, what is still owed to update()'s return value -- after the source has run whatever it had queued.
     ViterbiDecoder_Core(const ViterbiDecoder_Core& other) : m_branch_table(other.m_branch_table), m_config(other.m_config) {
         const_cast<ViterbiDecoder_Core&>(other).flush_pending();
+        const_cast<ViterbiDecoder_Core&>(other).fetch_device_rows();      // the copy starts from host rows that are complete
         vit_hip_info info;
         viterbi_hip_detail::require_ok(vit_hip_get_info(other.m_hip, &info), "vit_hip_get_info");
         viterbi_hip_detail::require_ok(
@@ -116,9 +117,7 @@ public:
             "vit_hip_create");
         m_metrics = other.m_metrics;
         m_decisions = other.m_decisions;
-        const viterbi_hip_detail::FlushHook hook{&ViterbiDecoder_Core::flush_hook, this};
-        m_metrics.set_flush_hook(hook);
-        m_decisions.set_flush_hook(hook);
+        install_hooks();
         m_current_decoded_bit = other.m_current_decoded_bit;
         m_unreported_renormalisation = other.m_unreported_renormalisation;
         m_exact_update_return = other.m_exact_update_return;
@@ -128,6 +127,7 @@ public:
     // number of decoded (information) bits kept for traceback; the K-1 tail steps are added on top
     void set_traceback_length(size_t traceback_length) {
         flush_pending();
+        fetch_device_rows();
         const size_t rows = traceback_length + TOTAL_STATE_BITS;
         m_decisions.resize(rows);
         if (m_current_decoded_bit > rows) m_current_decoded_bit = rows;
@@ -147,6 +147,7 @@ public:
         // that frame's exact total collects it with take_unreported_renormalisation() BEFORE reset(), or streams in exact mode
         // (set_exact_update_return), where nothing is ever owed.
         flush_pending();
+        m_dropped_renormalisation = m_unreported_renormalisation;      // readable afterwards: last_dropped_renormalisation()
         m_unreported_renormalisation = 0;
         m_current_decoded_bit = 0;
         error_t* m = m_metrics.raw_old();
@@ -160,9 +161,41 @@ public:
         assert(m_current_decoded_bit >= total_bits + TOTAL_STATE_BITS);
         assert(end_state < NUMSTATES);
         flush_pending();
+        if (m_dev_begin == 0 && m_dev_end >= total_bits + TOTAL_STATE_BITS) {
+            // every row the traceback reads was made on the device and is still there: no row travels (and if the update that
+            // completed the frame already chained back exactly these bits, no kernel runs either)
+            viterbi_hip_detail::require_ok(vit_hip_chainback_host_lazy(m_hip, total_bits, end_state, bytes_out), "vit_hip_chainback_host_lazy");
+            return;
+        }
+        fetch_device_rows();
         viterbi_hip_detail::require_ok(vit_hip_chainback_host(m_hip, m_decisions.raw_row(0), total_bits, end_state, bytes_out),
                                        "vit_hip_chainback_host");
     }
+
+    // ---- where the decision rows live ------------------------------------------------------------------------------------------
+    // update() leaves the rows it computes on the DEVICE (vit_hip_update_host_lazy): rows [m_dev_begin, m_dev_end) of m_decisions are
+    // stale on the host and authoritative in the handle's row store; every other row is authoritative on the host.  Reading
+    // m_decisions[row] fetches the stale rows first; a MUTABLE m_decisions[row] (the caller may write through it), resize and copy
+    // also hand authority back to the host, after which chainback() uploads the host rows as the reference's does.
+    void run_update(const soft_t* symbols, size_t steps, size_t first_row, uint64_t* renorm) {
+        if (m_dev_end > m_dev_begin && (first_row > m_dev_end || first_row + steps < m_dev_begin)) fetch_device_rows();   // not adjacent: one range only
+        viterbi_hip_detail::require_ok(
+            vit_hip_update_host_lazy(m_hip, m_metrics.raw_old(), symbols, steps, first_row, get_traceback_length(), 0, renorm),
+            "vit_hip_update_host_lazy");
+        if (m_dev_end == m_dev_begin) { m_dev_begin = first_row; m_dev_end = first_row + steps; }
+        else {
+            if (first_row < m_dev_begin) m_dev_begin = first_row;
+            if (first_row + steps > m_dev_end) m_dev_end = first_row + steps;
+        }
+    }
+    void fetch_device_rows() {
+        if (m_dev_end == m_dev_begin) return;
+        const size_t b = m_dev_begin, e = m_dev_end < m_decisions.size() ? m_dev_end : m_decisions.size();
+        m_dev_begin = m_dev_end = 0;                            // first: raw accesses below must not re-enter
+        if (e > b)
+            viterbi_hip_detail::require_ok(vit_hip_fetch_decisions_host(m_hip, b, e - b, m_decisions.raw_row(b)), "vit_hip_fetch_decisions_host");
+    }
+    size_t rows_on_device() const { return m_dev_end - m_dev_begin; }
 
     vit_hip_handle hip_handle() const { return m_hip; }
     // the kernel plan behind this decoder and, where it is the slow compatibility plan, how to get a faster one (vit_hip_plan_note)
@@ -203,9 +236,7 @@ public:
         const size_t steps = m_pending_steps, first_row = m_current_decoded_bit - steps;
         m_pending_steps = 0;                                   // first: the accessors below must not re-enter
         uint64_t renorm = 0;
-        viterbi_hip_detail::require_ok(
-            vit_hip_update_host(m_hip, m_metrics.raw_old(), m_pending_symbols.data(), steps, m_decisions.raw_row(first_row), &renorm),
-            "vit_hip_update_host");
+        run_update(m_pending_symbols.data(), steps, first_row, &renorm);
         m_pending_symbols.clear();
         m_unreported_renormalisation += renorm;
     }
@@ -217,6 +248,9 @@ public:
         m_unreported_renormalisation = 0;
         return v;
     }
+    // what the last reset() dropped (see reset()): non-zero only when a frame shorter than the traceback buffer was streamed in short
+    // calls and nobody collected its tail -- a caller that logs per-frame totals can assert on it or add it to the frame it belongs to
+    uint64_t last_dropped_renormalisation() const { return m_dropped_renormalisation; }
     size_t pending_steps() const { return m_pending_steps; }
 
 public:
@@ -228,10 +262,22 @@ public:
 
 private:
     static void flush_hook(void* self) { static_cast<ViterbiDecoder_Core*>(self)->flush_pending(); }
+    static void rows_hook(void* self) {
+        static_cast<ViterbiDecoder_Core*>(self)->flush_pending();
+        static_cast<ViterbiDecoder_Core*>(self)->fetch_device_rows();
+    }
+    void install_hooks() {
+        m_metrics.set_flush_hook(viterbi_hip_detail::FlushHook{&ViterbiDecoder_Core::flush_hook, this});
+        // reading or writing a row through m_decisions: queued steps run, device-resident rows come home
+        m_decisions.set_flush_hook(viterbi_hip_detail::FlushHook{&ViterbiDecoder_Core::rows_hook, this});
+        m_decisions.set_write_hook(viterbi_hip_detail::FlushHook{&ViterbiDecoder_Core::rows_hook, this});
+    }
     vit_hip_handle m_hip = nullptr;
+    size_t m_dev_begin = 0, m_dev_end = 0;       // rows [begin, end) of m_decisions are stale here and live in the handle's device row store
     std::vector<soft_t> m_pending_symbols;
     size_t m_pending_steps = 0;
     uint64_t m_unreported_renormalisation = 0;
+    uint64_t m_dropped_renormalisation = 0;
 #ifdef VITERBI_HIP_EXACT_UPDATE_RETURN
     bool m_exact_update_return = true;
 #else

@@ -37,10 +37,9 @@ public:
         }
         base.flush_pending();
         uint64_t renorm = 0;
-        viterbi_hip_detail::require_ok(
-            vit_hip_update_host(base.hip_handle(), base.m_metrics.raw_old(), symbols, total_decoded_bits,
-                                base.m_decisions.raw_row(base.m_current_decoded_bit), &renorm),
-            "vit_hip_update_host");
+        // one launch; the rows stay on the device until somebody reads m_decisions (viterbi_decoder_core.h: run_update), and a call
+        // that completes the frame also decodes it (chainback(traceback length, end state 0) then costs a memcpy)
+        base.run_update(symbols, total_decoded_bits, base.m_current_decoded_bit, &renorm);
         base.m_current_decoded_bit += total_decoded_bits;
         return sum_error_t(renorm + base.take_unreported_renormalisation());
     }

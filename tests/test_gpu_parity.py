@@ -86,6 +86,42 @@ def test_ragged_lengths_and_states(oracle, plan):
     check_batch_against_oracle(oracle, code, "SOFT16", 4, 256, 3.0, seed=9, plan=plan, n_steps=100)
 
 
+@pytest.mark.parametrize("K,R,G,decode_type,plan,cases", [
+    (7, 2, (0o155, 0o117), "SOFT16", _lib.PLAN_REG, [(33, 13), (70, 100), (17, 257), (130, 1001), (5, 4099)]),
+    (7, 2, (0o155, 0o117), "HARD8", _lib.PLAN_REG, [(33, 1029), (3, 7)]),
+    (9, 2, (0o753, 0o561), "SOFT16", _lib.PLAN_REG, [(33, 13), (35, 257), (130, 1001), (5, 2601)]),
+    (9, 4, (0o765, 0o671, 0o513, 0o473), "SOFT8", _lib.PLAN_REG, [(9, 101), (34, 1027)]),
+    (5, 2, (0o27, 0o31), "SOFT16", _lib.PLAN_REG, [(130, 13), (70, 1001)]),
+    (3, 2, (0o7, 0o5), "SOFT8", _lib.PLAN_REG, [(130, 9), (70, 1003)]),
+    (11, 2, (0o3345, 0o3613), "SOFT16", _lib.PLAN_LDS2, [(3, 13), (5, 257), (4, 1001)]),
+    (10, 2, (0o1167, 0o1545), "SOFT8", _lib.PLAN_LDS2, [(3, 13), (7, 257), (5, 1001)]),
+    (13, 2, (0o10533, 0o17661), "HARD8", _lib.PLAN_LDS2, [(3, 101), (2, 515)]),
+    (15, 6, (0o42631, 0o47245, 0o56507, 0o73363, 0o77267, 0o64537), "SOFT16", _lib.PLAN_LDS2, [(3, 13), (2, 257), (3, 1001)]),
+    (16, 2, (46749, 58851), "SOFT16", _lib.PLAN_LDS2, [(2, 101)]),
+    (6, 2, (0o65, 0o57), "SOFT16", _lib.PLAN_LDS, [(3, 13), (5, 257)]),
+])
+def test_ragged_bit_lengths_on_every_plan(oracle, K, R, G, decode_type, plan, cases):
+    """total_bits % 8 != 0 on the BATCHED route of every kernel plan (pinned by one K = 7 fixture only): the partial last
+    byte is filled from the end state as ViterbiTracebackBuffer does (core.h:87-153), per-frame start / end states, frame counts that
+    leave partial tiles, lengths on both sides of the chainback kernels' 32- / 1024-step iterations.  Noisy symbols of a frame
+    generated at the next whole-byte length, cut to L + K - 1 steps."""
+    from viterbidecodercpp_amd import Code, synth
+    from tests.helpers import make_table_config
+
+    code = Code(f"K{K}R{R}", K, R, tuple(G))
+    pc, _, _ = make_table_config(code, decode_type)
+    rng = np.random.default_rng(K * 100 + R)
+    for F, L in cases:
+        assert L % 8 != 0
+        L8 = (L + 7) // 8 * 8
+        _, sym = synth.make_frames_numpy(code, pc, F, L8, 2.0, seed=L + F)
+        sym = np.ascontiguousarray(sym[:, :L + K - 1])
+        ss = rng.integers(0, code.num_states, F).astype(np.int32)
+        es = rng.integers(0, code.num_states, F).astype(np.int32)
+        dec = check_batch_against_oracle(oracle, code, decode_type, F, L, None, seed=0, plan=plan, sym=sym, start_state=ss, end_state=es)
+        assert dec.plan == plan
+
+
 @pytest.mark.parametrize("plan", [_lib.PLAN_LDS, _lib.PLAN_AUTO])
 @pytest.mark.parametrize("decode_type", ["SOFT16", "HARD8"])
 def test_out_of_range_symbols_wrap(oracle, plan, decode_type):

@@ -205,3 +205,37 @@ def test_traffic_json_follows_from_its_sources():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     for key, e in json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).items():
         assert os.path.exists(os.path.join(ROOT, e["source"])), (key, e["source"])
+
+
+def test_reference_parse_benchmark_reads_the_tools_records(capsys, monkeypatch):
+    """INTEGRATION.md says the reference's examples/parse_benchmark.py digests viterbidecodercpp_amd.tools.run_benchmark's output
+    once `SIMD_HIP = 4` joins its SimdType enum.  Checked with the reference's own script, imported from where it lies (build container
+    only: nothing of it travels), that one entry added, and a committed record of the tool (sample lists cut to 64 entries)."""
+    import glob
+    import importlib.util
+    from enum import Enum
+
+    script = "/root/reference/examples/parse_benchmark.py"
+    if not os.path.exists(script):
+        pytest.skip("reference tree absent")
+    records = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_run_benchmark_hip_raw.json")))
+    assert records, "no committed run_benchmark record"
+    spec = importlib.util.spec_from_file_location("ref_parse_benchmark", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # the maintainer's one-line edit: one more entry in the enum
+    mod.SimdType = Enum("SimdType", {**{e.name: e.value for e in mod.SimdType}, "SIMD_HIP": 4})
+    monkeypatch.setattr("sys.argv", ["parse_benchmark.py", records[-1]])
+    mod.main()
+    out = capsys.readouterr().out
+    recs = json.load(open(records[-1]))
+    assert len(recs) == 24 and out.count("simd=simd_hip") == 24
+    assert "name='Voyager',K=7,R=2,decode=SOFT16" in out and "name='Cassini',K=15,R=6,decode=HARD8" in out
+    import re as _re
+    rates = [float(x) for x in _re.findall(r"update    = ([0-9.]+) ± [0-9.]+ gigasymbols/s", out)]
+    assert len(rates) >= 20 and max(rates) > 100      # K = 3: hundreds of Gsym/s on one card
+    # unmodified, the script refuses the strategy name -- that IS the documented edit
+    mod2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod2)
+    with pytest.raises(Exception, match="invalid simd type"):
+        mod2.Sample(recs[0])

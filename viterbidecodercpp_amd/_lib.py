@@ -28,7 +28,7 @@ EXPORTS = [
     "vit_hip_pipeline_destroy", "vit_hip_pipeline_get_schedule", "vit_hip_pipeline_last_workspace", "vit_hip_pipeline_set_timing", "vit_hip_pipeline_get_timing",
     "vit_hip_pipeline_wait_event", "vit_hip_get_kernel_resources", "vit_hip_list_kernels",
     "vit_hip_chainback_batch_ex", "vit_hip_pipeline_create_ex", "vit_hip_pipeline_get_schedule_v2", "vit_hip_plan_note",
-    "vit_hip_precompile",
+    "vit_hip_precompile", "vit_hip_update_host_lazy", "vit_hip_chainback_host_lazy", "vit_hip_fetch_decisions_host",
 ]
 
 
@@ -97,6 +97,9 @@ def load():
     L.vit_hip_set_plan.argtypes = [vp, i32]
     L.vit_hip_plan_note.argtypes = [vp]
     L.vit_hip_plan_note.restype = C.c_char_p
+    L.vit_hip_update_host_lazy.argtypes = [vp, vp, vp, sz, sz, sz, sz, C.POINTER(C.c_uint64)]
+    L.vit_hip_chainback_host_lazy.argtypes = [vp, sz, sz, vp]
+    L.vit_hip_fetch_decisions_host.argtypes = [vp, sz, sz, vp]
     L.vit_hip_precompile.argtypes = [i32, i32, C.POINTER(C.c_uint32), i32, C.c_char_p, C.c_char_p, sz]
     L.vit_hip_blob_bytes.restype = sz
     L.vit_hip_blob_bytes.argtypes = [i32, i32, i32, i32]

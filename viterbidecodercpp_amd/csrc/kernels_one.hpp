@@ -48,10 +48,14 @@ struct OneUpdateArgs {
     const uint16_t* pattern;     // [H] bit i = (branch_table[i][j] == high)
     int32_t K, n_steps;
     DevConfig cfg;
+    // frame route (one_frame_kernel): the metrics to start from travel IN THE KERNEL ARGUMENTS (128 bytes, device domain: u8 metrics
+    // already in the high byte) -- no load from host memory in front of the first step; metrics_io is then only written
+    int32_t metrics_in_args;
+    uint16_t metrics_in[64];
 };
 
 template <int R, int SHIFT>
-__global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
+__device__ __forceinline__ void one_update_body(const OneUpdateArgs& a) {
     const int N = 1 << (a.K - 1);
     const int H = N >> 1;
     const int lane = threadIdx.x & 63;
@@ -70,7 +74,8 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
     for (int i = 0; i < R; ++i) rot[i] = ((p >> i) & 1u) ? 16u : 0u;
 
     uint32_t m;                                                 // the path metric of state `s`, low 16 bits
-    if (SHIFT) m = (uint32_t)(((const uint8_t*)a.metrics_io)[s]) << 8;
+    if (a.metrics_in_args) m = a.metrics_in[s];
+    else if (SHIFT) m = (uint32_t)(((const uint8_t*)a.metrics_io)[s]) << 8;
     else m = ((const uint16_t*)a.metrics_io)[s];
 
     // The symbols of a step are the same for every lane.  Per group of 64 steps lane l forms (|low - y_i| | |high - y_i| << 16) of
@@ -96,6 +101,20 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
     const uint32_t XA = b_in ? 0xFFFFu : 0u, CA = b_in ? max_error + 1u : 0u;
     const uint32_t XB = b_in ? 0u : 0xFFFFu, CB = b_in ? 0u : max_error + 1u;
 
+    // state 0's metric after the last step run, as a signed value: -1 = "no step yet" (below every threshold, 0 included: the
+    // reference tests after a step, never the metrics a call starts from)
+    uint32_t m_state0 = 0xFFFFFFFFu;
+    auto renormalise = [&]() __attribute__((always_inline)) {
+        uint32_t mn = m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mn, off);
+            mn = o < mn ? o : mn;
+        }
+        m = (m - mn) & 0xFFFFu;
+        acc += (uint64_t)(mn >> SHIFT);
+    };
+
     uint32_t ap_next[R];
     symbol_pairs(0, ap_next);
     for (int t0 = 0; t0 < a.n_steps; t0 += 64) {
@@ -112,8 +131,19 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
             constexpr int k = decltype(kc)::value;
             if (!decltype(partial_c)::value || k < nb) {
             // ---- the dependent chain of the step starts here: the predecessors' metrics ----
-            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(addr0, (int)m);
-            const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr1, (int)m);
+            uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(addr0, (int)m);
+            uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr1, (int)m);
+            // renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153): state 0 is lane 0.  The test of the PREVIOUS
+            // step's result sits HERE, behind the issue of this step's fetches: v_readfirstlane -> s_cmp -> s_cbranch used to end every
+            // step's chain (the next fetch could not issue before the branch had resolved: ~30 of a step's ~165 clocks); now they
+            // resolve while the fetches travel.  The subtraction commutes with nothing it skips -- the decisions of the step that
+            // tripped are final, and the only readers of the renormalised metrics are this step's fetches, which the rare branch
+            // simply issues again from the corrected register
+            if (__builtin_expect((int32_t)m_state0 >= (int32_t)threshold, 0)) {
+                renormalise();
+                pa = (uint32_t)__builtin_amdgcn_ds_bpermute(addr0, (int)m);
+                pb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr1, (int)m);
+            }
             // ... while they travel: e = sum_i |expected_i - y_i|  (scalar.h:66-73) from lane k's packed pairs
             uint32_t e = 0;
 #pragma unroll
@@ -130,18 +160,7 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
             const uint64_t word = __ballot(d) & live;                          // :131-134
             asm("v_writelane_b32 %0, %1, %2" : "+v"(w_lo) : "s"((uint32_t)word), "n"(k));
             asm("v_writelane_b32 %0, %1, %2" : "+v"(w_hi) : "s"((uint32_t)(word >> 32)), "n"(k));
-            // renormalise when new_metric[0] >= threshold  (scalar.h:48-50, :139-153): state 0 is lane 0
-            const uint32_t m_state0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-            if (__builtin_expect(m_state0 >= threshold, 0)) {
-                uint32_t mn = m;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)mn, off);
-                    mn = o < mn ? o : mn;
-                }
-                m = (m - mn) & 0xFFFFu;
-                acc += (uint64_t)(mn >> SHIFT);
-            }
+            m_state0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);      // tested behind the NEXT step's fetches (or after the last step)
             }
         });
         };
@@ -150,6 +169,7 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
         // the group's rows: one coalesced store (512 bytes when the group is whole)
         if (lane < nb) a.decisions[(size_t)t0 + (size_t)lane] = ((uint64_t)w_hi << 32) | w_lo;
     }
+    if ((int32_t)m_state0 >= (int32_t)threshold) renormalise();      // the last step's test
 
     if (lane < N) {
         if (SHIFT) ((uint8_t*)a.metrics_io)[lane] = (uint8_t)(m >> 8);
@@ -157,6 +177,9 @@ __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) {
     }
     if (lane == 0) a.renorm_sum[0] = acc;
 }
+
+template <int R, int SHIFT>
+__global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) { one_update_body<R, SHIFT>(a); }
 
 struct OneChainbackArgs {
     const uint64_t* decisions;   // [L + K-1] words
@@ -176,8 +199,8 @@ struct OneChainbackArgs {
 // of a millisecond a 8192-step dependent chain costs one wavefront.
 constexpr int ONE_CB_CHUNK = 8192;       // rows staged per pass (64 KiB of LDS)
 constexpr int ONE_CB_WARM = 64;          // speculative steps in front of a segment
-__global__ void __launch_bounds__(64) one_chainback_kernel(OneChainbackArgs a) {
-    extern __shared__ uint64_t one_rows[];                  // [ONE_CB_CHUNK + 64 + 8] rows (one pad row per segment), then the chunk's output bytes
+__device__ __forceinline__ void one_chainback_body(const OneChainbackArgs& a, uint64_t* one_rows) {
+    // one_rows: [ONE_CB_CHUNK + 64 + 8] rows (one pad row per segment), then the chunk's output bytes
     uint8_t* const obytes = (uint8_t*)(one_rows + ONE_CB_CHUNK + 64 + 8);
     const int lane = threadIdx.x & 63;
     const int TSB = a.K - 1;
@@ -248,6 +271,40 @@ __global__ void __launch_bounds__(64) one_chainback_kernel(OneChainbackArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(64) one_chainback_kernel(OneChainbackArgs a) {
+    extern __shared__ uint64_t one_rows_smem[];
+    one_chainback_body(a, one_rows_smem);
+}
+
+// The FRAME route of the header-level drop-in (vit_hip_update_host_lazy): update() and the chainback() that will follow it in ONE
+// launch -- a single decoder object's reset -> update -> chainback (examples/run_simple.cpp:76-80) then costs one kernel start
+// instead of two launches, two synchronisations and four staging copies.  The symbols are read straight from pinned host-mapped
+// memory (lane l fetches step l's, a 64-step group ahead of their use: the PCIe round trip hides behind the 4.6 us a group takes),
+// the decision rows stay in HBM (the host fetches them only if somebody reads m_decisions), metrics, renormalisation sum and the
+// decoded bytes are written to host-mapped memory, and the last thing the wavefront does is a system-scope release store of `seq`
+// into the word the host is polling.
+struct OneFrameArgs {
+    OneUpdateArgs u;
+    OneChainbackArgs c;
+    int32_t do_chainback;
+    uint32_t seq;
+    uint32_t* done;              // host-mapped
+};
+template <int R, int SHIFT>
+__global__ void __launch_bounds__(64) one_frame_kernel(OneFrameArgs a) {
+    extern __shared__ uint64_t one_rows_smem[];
+    one_update_body<R, SHIFT>(a.u);
+    if (a.do_chainback) {
+        // the rows this wavefront stored are read back by the same wavefront: stores complete and visible, no stale lines
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __syncthreads();
+        one_chainback_body(a.c, one_rows_smem);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");           // system scope: everything above is visible to the host ...
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.done, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before this
+}
+
 constexpr size_t one_chainback_lds_bytes() { return ((size_t)ONE_CB_CHUNK + 64 + 8) * 8 + ONE_CB_CHUNK / 8 + 8; }
 inline bool one_supported(int K, int R) { return K >= 2 && K <= 7 && R >= 1 && R <= 8; }
 
@@ -264,6 +321,23 @@ inline int one_launch_update(int R, const OneUpdateArgs& a, hipStream_t st) {
         case 8: hipLaunchKernelGGL((one_update_kernel<8, SHIFT>), dim3(1), dim3(64), 0, st, a); break;
         default: return -1;
     }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int SHIFT>
+inline int one_launch_frame(int R, const OneFrameArgs& a, hipStream_t st) {
+    const size_t smem = a.do_chainback ? one_chainback_lds_bytes() : 0;
+#define VIT_ONE_FRAME_CASE(r)                                                                                                              \
+    case r:                                                                                                                                \
+        if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(one_frame_kernel<r, SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1; \
+        hipLaunchKernelGGL((one_frame_kernel<r, SHIFT>), dim3(1), dim3(64), smem, st, a);                                                  \
+        break;
+    switch (R) {
+        VIT_ONE_FRAME_CASE(1) VIT_ONE_FRAME_CASE(2) VIT_ONE_FRAME_CASE(3) VIT_ONE_FRAME_CASE(4)
+        VIT_ONE_FRAME_CASE(5) VIT_ONE_FRAME_CASE(6) VIT_ONE_FRAME_CASE(7) VIT_ONE_FRAME_CASE(8)
+        default: return -1;
+    }
+#undef VIT_ONE_FRAME_CASE
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -84,6 +84,14 @@ struct vit_hip_decoder {
     size_t scratch_bytes = 0;
     void* h_stage = nullptr;        // pinned host staging: one H2D and one D2H per host-route call
     size_t stage_bytes = 0;
+    // frame route (vit_hip_update_host_lazy / vit_hip_chainback_host_lazy / vit_hip_fetch_decisions_host)
+    uint64_t* d_rows = nullptr;     // decision rows of the handle's ONE host-route frame, [row][W], kept on the device
+    size_t rows_cap = 0;            // rows allocated
+    void* h_map = nullptr;          // pinned AND host-mapped: [64 B control | 192 B | metrics | symbols | decoded bytes]
+    size_t map_bytes = 0;
+    uint32_t seq = 0;               // the value the next frame kernel stores into the control word when it is done
+    bool spec_valid = false;        // the decoded bytes in h_map are those of chainback(spec_bits, spec_end) over the rows in d_rows
+    size_t spec_bits = 0, spec_end = 0, spec_off = 0;
 };
 
 namespace {
@@ -212,6 +220,36 @@ int ensure_stage(vit_hip_handle h, size_t bytes) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// frame route: the device row store holds rows [0, rows) of the frame (contents kept when it grows)
+int ensure_rows(vit_hip_handle h, size_t rows) {
+    if (rows <= h->rows_cap) return VIT_HIP_OK;
+    const size_t want = rows + rows / 2 + 64;
+    uint64_t* p = nullptr;
+    VIT_HIP_CHECK(hipMalloc((void**)&p, want * (size_t)h->W * 8));
+    if (h->d_rows) {
+        VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (hipMemcpy(p, h->d_rows, h->rows_cap * (size_t)h->W * 8, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(p); return fail(VIT_HIP_ERR_RUNTIME, "row store copy failed"); }
+        (void)hipFree(h->d_rows);
+    }
+    h->d_rows = p;
+    h->rows_cap = want;
+    return VIT_HIP_OK;
+}
+
+int ensure_map(vit_hip_handle h, size_t bytes) {
+    if (bytes <= h->map_bytes) return VIT_HIP_OK;
+    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->h_map) VIT_HIP_CHECK(hipHostFree(h->h_map));
+    h->h_map = nullptr;
+    h->map_bytes = 0;
+    h->spec_valid = false;
+    const size_t want = bytes + bytes / 2 + 4096;
+    VIT_HIP_CHECK(hipHostMalloc(&h->h_map, want, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->h_map, 0, 256);
+    h->map_bytes = want;
+    return VIT_HIP_OK;
+}
 
 int read_soft(const void* p, size_t idx, int soft_bytes) {
     return soft_bytes == 1 ? (int)((const int8_t*)p)[idx] : (int)((const int16_t*)p)[idx];
@@ -384,6 +422,8 @@ int vit_hip_destroy(vit_hip_handle h) {
     if (h->d_pattern) (void)hipFree(h->d_pattern);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_map) (void)hipHostFree(h->h_map);
+    if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return VIT_HIP_OK;
@@ -1366,6 +1406,157 @@ int vit_hip_chainback_host(vit_hip_handle h, const uint64_t* decisions, size_t L
     VIT_HIP_CHECK(hipMemcpyAsync(hs + dec_b, base + dec_b, out_bytes, hipMemcpyDeviceToHost, h->stream));
     VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
     memcpy(bytes_out, hs + dec_b, out_bytes);
+    return VIT_HIP_OK;
+}
+
+// ---- frame route: ONE launch for update() + the chainback() that follows, rows kept on the device -----------------------------
+int vit_hip_update_host_lazy(vit_hip_handle h, void* metrics_inout, const void* symbols, size_t n_steps, size_t first_row,
+                             size_t speculate_bits, size_t speculate_end_state, uint64_t* renorm_sum_out) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (!metrics_inout) return fail(VIT_HIP_ERR_INVALID_ARG, "metrics_inout is NULL");
+    if (renorm_sum_out) *renorm_sum_out = 0;
+    if (n_steps == 0) return VIT_HIP_OK;
+    if (!symbols) return fail(VIT_HIP_ERR_INVALID_ARG, "symbols is NULL");
+    if (n_steps > 0x7FFFFFF0u || first_row > 0x7FFFFFF0u) return fail(VIT_HIP_ERR_INVALID_ARG, "n_steps / first_row too large");
+    if (speculate_bits > 0 && speculate_end_state >= (size_t)h->N) return fail(VIT_HIP_ERR_INVALID_ARG, "speculate_end_state out of range");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    h->spec_valid = false;                                   // whatever was decoded ahead belonged to the rows as they were
+    int rc = ensure_rows(h, first_row + n_steps);
+    if (rc != VIT_HIP_OK) return rc;
+    const size_t sym_bytes = n_steps * (size_t)h->R * (size_t)h->soft_bytes;
+    const size_t met_bytes = (size_t)h->N * (size_t)h->error_bytes;
+    if (!vit::one_supported(h->K, h->R)) {
+        // K > 7: the LDS plan on one frame, as vit_hip_update_host runs it -- but the rows go straight into the device row store
+        const size_t met_b = align_up(met_bytes, 256), rs_b = 256, sym_b = align_up(sym_bytes, 256);
+        rc = ensure_scratch(h, met_b + rs_b + sym_b);
+        if (rc != VIT_HIP_OK) return rc;
+        rc = ensure_stage(h, met_b + rs_b + sym_b);
+        if (rc != VIT_HIP_OK) return rc;
+        uint8_t* base = (uint8_t*)h->d_scratch;
+        uint8_t* hs = (uint8_t*)h->h_stage;
+        memcpy(hs, metrics_inout, met_bytes);
+        memcpy(hs + met_b + rs_b, symbols, sym_bytes);
+        VIT_HIP_CHECK(hipMemcpyAsync(base, hs, met_b + rs_b + sym_bytes, hipMemcpyHostToDevice, h->stream));
+        rc = lds_update(h, base + met_b + rs_b, n_steps * (size_t)h->R, 1, n_steps, n_steps, 0, h->d_rows + first_row * (size_t)h->W, base, false,
+                        (uint64_t*)(base + met_b), nullptr, h->stream);
+        if (rc != VIT_HIP_OK) return rc;
+        VIT_HIP_CHECK(hipMemcpyAsync(hs, base, met_b + rs_b, hipMemcpyDeviceToHost, h->stream));
+        VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(metrics_inout, hs, met_bytes);
+        if (renorm_sum_out) memcpy(renorm_sum_out, hs + met_b, 8);
+        return VIT_HIP_OK;
+    }
+    const bool spec = speculate_bits > 0 && first_row + n_steps == speculate_bits + (size_t)h->K - 1 && speculate_bits <= 0xFFFFFFF0ull;
+    const size_t met_off = 256, sym_off = met_off + align_up(met_bytes, 256), out_off = sym_off + align_up(sym_bytes, 256);
+    const size_t out_bytes = spec ? (speculate_bits + 7) / 8 : 0;
+    rc = ensure_map(h, out_off + align_up(out_bytes, 256));
+    if (rc != VIT_HIP_OK) return rc;
+    uint8_t* hm = (uint8_t*)h->h_map;
+    void* dm_v = nullptr;
+    VIT_HIP_CHECK(hipHostGetDevicePointer(&dm_v, h->h_map, 0));
+    uint8_t* dm = (uint8_t*)dm_v;
+    memcpy(hm + sym_off, symbols, sym_bytes);
+    vit::OneFrameArgs fa{};
+    fa.u.symbols = dm + sym_off;
+    fa.u.sym_total_bytes = sym_bytes;
+    fa.u.decisions = h->d_rows + first_row;                  // W == 1 here
+    fa.u.metrics_io = dm + met_off;
+    fa.u.renorm_sum = (uint64_t*)(dm + 64);
+    fa.u.pattern = h->d_pattern;
+    fa.u.K = h->K;
+    fa.u.n_steps = (int)n_steps;
+    fa.u.cfg = h->cfg;
+    fa.u.metrics_in_args = 1;
+    for (int s = 0; s < 64; ++s) {
+        const int t = s & (h->N - 1);
+        fa.u.metrics_in[s] = h->error_bytes == 1 ? (uint16_t)((uint32_t)((const uint8_t*)metrics_inout)[t] << 8) : ((const uint16_t*)metrics_inout)[t];
+    }
+    fa.do_chainback = spec ? 1 : 0;
+    fa.c.decisions = h->d_rows;
+    fa.c.out = dm + out_off;
+    fa.c.end_state = (uint32_t)speculate_end_state;
+    fa.c.L = (uint32_t)speculate_bits;
+    fa.c.K = h->K;
+    fa.seq = ++h->seq ? h->seq : ++h->seq;                   // never 0
+    fa.done = (uint32_t*)dm;
+    volatile uint32_t* done = (volatile uint32_t*)hm;
+    if ((h->shift ? vit::one_launch_frame<8>(h->R, fa, h->stream) : vit::one_launch_frame<0>(h->R, fa, h->stream)) != 0)
+        return fail(VIT_HIP_ERR_RUNTIME, "frame kernel launch failed");
+    // the kernel's last act is a system-scope release store of seq into the control word: poll it (a stream synchronisation costs more
+    // than the whole chainback); a kernel that never gets there shows up in the stream's status
+    const uint32_t seq = fa.seq;
+    for (uint64_t spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if ((spins & 0xFFFFu) == 0xFFFFu) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q != hipErrorNotReady) {
+                if (q != hipSuccess) return fail(VIT_HIP_ERR_RUNTIME, std::string("frame kernel: ") + hipGetErrorString(q));
+                if (__atomic_load_n(done, __ATOMIC_ACQUIRE) != seq) return fail(VIT_HIP_ERR_RUNTIME, "frame kernel finished without reporting");
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    memcpy(metrics_inout, hm + met_off, met_bytes);
+    if (renorm_sum_out) memcpy(renorm_sum_out, hm + 64, 8);
+    if (spec) { h->spec_valid = true; h->spec_bits = speculate_bits; h->spec_end = speculate_end_state; h->spec_off = out_off; }
+    return VIT_HIP_OK;
+}
+
+int vit_hip_fetch_decisions_host(vit_hip_handle h, size_t first_row, size_t n_rows, uint64_t* decisions_out) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (n_rows == 0) return VIT_HIP_OK;
+    if (!decisions_out) return fail(VIT_HIP_ERR_INVALID_ARG, "decisions_out is NULL");
+    if (first_row + n_rows > h->rows_cap || !h->d_rows) return fail(VIT_HIP_ERR_INVALID_ARG, "rows outside the device row store");
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    VIT_HIP_CHECK(hipMemcpyAsync(decisions_out, h->d_rows + first_row * (size_t)h->W, n_rows * (size_t)h->W * 8, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return VIT_HIP_OK;
+}
+
+int vit_hip_chainback_host_lazy(vit_hip_handle h, size_t L, size_t end_state, uint8_t* bytes_out) {
+    if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
+    if (L == 0) return VIT_HIP_OK;
+    if (!bytes_out) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL buffer");
+    if (end_state >= (size_t)h->N) return fail(VIT_HIP_ERR_INVALID_ARG, "end_state out of range");
+    const size_t rows = L + (size_t)h->K - 1, out_bytes = (L + 7) / 8;
+    if (rows > h->rows_cap || !h->d_rows) return fail(VIT_HIP_ERR_INVALID_ARG, "the device row store does not hold L + K - 1 rows");
+    if (h->spec_valid && h->spec_bits == L && h->spec_end == end_state) {      // decoded by the launch that completed the frame
+        memcpy(bytes_out, (const uint8_t*)h->h_map + h->spec_off, out_bytes);
+        return VIT_HIP_OK;
+    }
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(VIT_HIP_ERR_RUNTIME, "hipSetDevice failed");
+    const size_t out_b = align_up(out_bytes, 256);
+    int rc = ensure_scratch(h, out_b + 256);
+    if (rc != VIT_HIP_OK) return rc;
+    rc = ensure_stage(h, out_b);
+    if (rc != VIT_HIP_OK) return rc;
+    uint8_t* base = (uint8_t*)h->d_scratch;
+    if (vit::one_supported(h->K, h->R)) {
+        if (L > 0xFFFFFFF0ull) return fail(VIT_HIP_ERR_INVALID_ARG, "L too large");
+        vit::OneChainbackArgs ca{};
+        ca.decisions = h->d_rows;
+        ca.out = base;
+        ca.end_state = (uint32_t)end_state;
+        ca.L = (uint32_t)L;
+        ca.K = h->K;
+        VIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vit::one_chainback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)vit::one_chainback_lds_bytes()));
+        hipLaunchKernelGGL(vit::one_chainback_kernel, dim3(1), dim3(64), vit::one_chainback_lds_bytes(), h->stream, ca);
+        VIT_HIP_CHECK(hipGetLastError());
+    } else {
+        uint32_t es = (uint32_t)end_state;
+        uint32_t* d_es = (uint32_t*)(base + out_b);
+        VIT_HIP_CHECK(hipMemcpyAsync(d_es, &es, 4, hipMemcpyHostToDevice, h->stream));
+        rc = lds_chainback(h, h->d_rows, 1, L, base, d_es, h->stream);
+        if (rc != VIT_HIP_OK) return rc;
+    }
+    VIT_HIP_CHECK(hipMemcpyAsync(h->h_stage, base, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    VIT_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(bytes_out, h->h_stage, out_bytes);
     return VIT_HIP_OK;
 }
 

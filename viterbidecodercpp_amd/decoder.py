@@ -143,6 +143,8 @@ class ViterbiDecoder_Core:
         self._metrics = np.zeros(self.NUMSTATES, dtype=config.error_dtype)
         self._decisions = np.zeros((0, self.TOTAL_BLOCKS), dtype=np.uint64)
         self._pending, self._pending_steps, self._unreported = [], 0, 0
+        self._dropped = 0
+        self._dev_begin = self._dev_end = 0     # rows [begin, end) of _decisions are stale here: they live in the handle's device row store
         self._exact_update_return = False
         self.m_current_decoded_bit = 0
         self.reset()
@@ -156,11 +158,28 @@ class ViterbiDecoder_Core:
 
     @property
     def m_decisions(self):
+        # the array handed out is writable: queued steps run, device-resident rows come home, the host copy is the authority again
         self.flush_pending()
+        self.fetch_device_rows()
         return self._decisions
+
+    def fetch_device_rows(self):
+        """update() leaves the rows it computes in the handle's device row store (vit_hip_update_host_lazy); this copies the stale
+        range back and makes the host rows authoritative (what reading m_decisions does)."""
+        b, e = self._dev_begin, min(self._dev_end, len(self._decisions))
+        self._dev_begin = self._dev_end = 0
+        if e > b:
+            rows = np.zeros((e - b, self.TOTAL_BLOCKS), dtype=np.uint64)
+            _lib.check(_lib.load().vit_hip_fetch_decisions_host(self._handle._h, b, e - b, rows.ctypes.data_as(C.c_void_p)))
+            self._decisions[b:e] = rows
+
+    @property
+    def rows_on_device(self) -> int:
+        return self._dev_end - self._dev_begin
 
     def set_traceback_length(self, traceback_length: int):
         self.flush_pending()
+        self.fetch_device_rows()
         new_length = traceback_length + self.TOTAL_STATE_BITS
         old = self._decisions
         self._decisions = np.zeros((new_length, self.TOTAL_BLOCKS), dtype=np.uint64)
@@ -187,18 +206,24 @@ class ViterbiDecoder_Core:
         # returned yet is DROPPED: a frame's tail never inflates the next frame's total (collect it with
         # take_unreported_renormalisation() before reset(), or stream in exact mode)
         self.flush_pending()
-        self._unreported = 0
+        self._dropped, self._unreported = self._unreported, 0
         self.m_current_decoded_bit = 0
         self._metrics[:] = self.m_config.initial_non_start_error
         self._metrics[starting_state & (self.NUMSTATES - 1)] = self.m_config.initial_start_error
 
     def _run(self, symbols, steps, first_row):
-        rows = np.zeros((steps, self.TOTAL_BLOCKS), dtype=np.uint64)
+        """one launch (vit_hip_update_host_lazy): the rows stay on the device; a call that completes the frame also chains it back for
+        (traceback length, end state 0), so that the chainback() behind it costs a memcpy"""
+        if self._dev_end > self._dev_begin and (first_row > self._dev_end or first_row + steps < self._dev_begin):
+            self.fetch_device_rows()             # not adjacent to the device-resident range: one range only
         rs = C.c_uint64(0)
-        _lib.check(_lib.load().vit_hip_update_host(self._handle._h, self._metrics.ctypes.data_as(C.c_void_p),
-                                                   symbols.ctypes.data_as(C.c_void_p), steps, rows.ctypes.data_as(C.c_void_p),
-                                                   C.byref(rs)))
-        self._decisions[first_row:first_row + steps] = rows
+        _lib.check(_lib.load().vit_hip_update_host_lazy(self._handle._h, self._metrics.ctypes.data_as(C.c_void_p),
+                                                        symbols.ctypes.data_as(C.c_void_p), steps, first_row,
+                                                        self.get_traceback_length(), 0, C.byref(rs)))
+        if self._dev_end == self._dev_begin:
+            self._dev_begin, self._dev_end = first_row, first_row + steps
+        else:
+            self._dev_begin, self._dev_end = min(self._dev_begin, first_row), max(self._dev_end, first_row + steps)
         return int(rs.value)
 
     def enqueue_steps(self, symbols, steps):
@@ -220,11 +245,22 @@ class ViterbiDecoder_Core:
         v, self._unreported = self._unreported, 0
         return v
 
+    def last_dropped_renormalisation(self) -> int:
+        """what the last reset() dropped: a renormalisation sum that had been computed (by a flush) but that no update() call had
+        returned and nobody had collected -- 0 unless a frame shorter than the traceback buffer was streamed in short calls"""
+        return self._dropped
+
     def chainback(self, total_bits: int, end_state: int = 0) -> np.ndarray:
         assert self.get_traceback_length() >= total_bits
         assert self.m_current_decoded_bit - self.TOTAL_STATE_BITS >= total_bits
         assert end_state < self.NUMSTATES
         out = np.zeros((total_bits + 7) // 8, dtype=np.uint8)
+        self.flush_pending()
+        if self._dev_begin == 0 and self._dev_end >= total_bits + self.TOTAL_STATE_BITS:
+            # every row the traceback reads is still on the device: nothing travels, and if the update that completed the frame
+            # already decoded exactly these bits no kernel runs either
+            _lib.check(_lib.load().vit_hip_chainback_host_lazy(self._handle._h, total_bits, end_state, out.ctypes.data_as(C.c_void_p)))
+            return out
         rows = np.ascontiguousarray(self.m_decisions[:total_bits + self.TOTAL_STATE_BITS])
         _lib.check(_lib.load().vit_hip_chainback_host(self._handle._h, rows.ctypes.data_as(C.c_void_p), total_bits,
                                                       end_state, out.ctypes.data_as(C.c_void_p)))
