@@ -244,6 +244,8 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     u32* const flag = wmin + 16;                               // [0] careful routine wanted for the next block; [2] scratch; [4] arrivals
     u32* const arrive = flag + 4;                              // wavefronts that have loaded their block's metrics, running total
     uint64_t* const rs_acc = (uint64_t*)(flag + 8);            // [2] sum of subtracted minima, frame A / B (thread 0 only)
+    u32* const sig = flag + 12;                                // [4] careful blocks: thread 0's per-stage "renormalise" word (slow_block)
+    u32 careful_seq = 0;                                       // careful stages run so far: the same count in every wavefront
     u32* const met = flag + 16;                                // [N], 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -835,6 +837,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         if constexpr (ASM_LS) __builtin_amdgcn_s_waitcnt(0xC07F);
     };
     // block-wide renormalisation of the registers (scalar.h:139-153) for the frames whose sign bit is set in `need`
+    u32 renorm_count = 0;                      // reductions run so far (block-uniform): picks the set of per-wavefront minima
     auto renormalise = [&](u32 need) __attribute__((always_inline)) {
         const u32 msk = ((need & 0x8000u) ? 0x0000FFFFu : 0u) | ((need & 0x80000000u) ? 0xFFFF0000u : 0u);
         u32 mn = mA[0];
@@ -846,9 +849,15 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));
-        if (lane == 0) wmin[wave] = mn;
+        // two sets of per-wavefront minima, used in turn (up to eight wavefronts: K <= 15): the barrier below is then the only one of a
+        // reduction -- the next reduction writes the other set, and the one after it cannot start before everybody has passed
+        // the next one's barrier, i.e. has long read this set
+        constexpr bool WMIN2 = NW <= 8;
+        u32* const wm = wmin + (WMIN2 ? (renorm_count & 1u) * 8u : 0u);
+        renorm_count += 1u;
+        if (lane == 0) wm[wave] = mn;
         __syncthreads();
-        for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wmin[w]);
+        for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wm[w]);
         const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
 #pragma unroll
         for (int i = 0; i < 16; ++i) mA[i] = l2_sub(mA[i], sub);
@@ -860,7 +869,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             rs_acc[0] += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
             rs_acc[1] += (uint64_t)((sub >> 16) >> SHIFT);
         }
-        __syncthreads();                      // wmin may be rewritten by the next reduction
+        if constexpr (!WMIN2) __syncthreads();   // one set only (K = 16): it may be rewritten by the next reduction
     };
     // the careful version of a block: stages [c_first, nst) with the threshold test and the reduction after EVERY stage; used
     // when the prediction says state 0 may cross the threshold inside the block, for the entry block of a resumed call
@@ -889,11 +898,24 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             constexpr int C = decltype(cc)::value;
             if (C >= c_first && C < nst) {
                 stage_all(cc, ws_base_of(t0));
-                // state 0 is register 0 of thread 0's first group after every stage
-                if (tid == 0) flag[2] = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
-                __syncthreads();
-                const u32 need = (u32)__builtin_amdgcn_readfirstlane((int)flag[2]);   // block-uniform: scalar branch
-                __syncthreads();
+                // state 0 is register 0 of thread 0's first group after every stage: thread 0 tells the other wavefronts whether a frame
+                // has to renormalise.  A ONE-WAY signal, not a barrier: nothing but this word passes between the stages of a careful
+                // block (the metrics stay in registers), so nobody waits for anybody but wavefront 0.  Slot C of the block holds
+                // (sequence number of the careful stage << 2 | the two frames' bits); the block's closing barrier separates this
+                // block's writes of a slot from the next block's.  (Round 5: two workgroup barriers per stage -- with the reference's
+                // 8-bit soft configuration 62 % of Cassini's blocks are careful ones: a frame renormalises every 8.5 steps.  Cassini
+                // SOFT8 4096 x 8192: 61.3 -> 59.0 ms.  Building the tables on the LAST four wavefronts, so that wavefront 0 reaches
+                // its word sooner, changed nothing -- 59.4: what is left of SOFT8's distance to HARD8's 50.4 ms is the reduction and
+                // the 32 subtractions themselves, about once per block.)
+                careful_seq += 1u;
+                if (tid == 0) {
+                    const u32 nb2 = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
+                    __hip_atomic_store(&sig[C], (careful_seq << 2) | ((nb2 >> 15) & 1u) | ((nb2 >> 30) & 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                u32 sv;
+                while (((sv = __hip_atomic_load(&sig[C], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != careful_seq) __builtin_amdgcn_s_sleep(1);
+                sv = (u32)__builtin_amdgcn_readfirstlane((int)sv);                    // block-uniform: scalar branch
+                const u32 need = ((sv & 1u) << 15) | ((sv & 2u) << 30);
                 if (need != 0) renormalise(need);
                 if (C == nst - 1) {
                     if (C == BLK - 1) {
