@@ -507,9 +507,10 @@ def dry_run(args, world, rank, affinity):
 
 def host_route(args):
     """BASELINE configs[0]: one frame through the drop-in's own call pattern (examples/run_simple.cpp:67-80) -- a single decoder
-    object whose state lives on the host, update() and chainback() each one GPU launch (csrc/kernels_one.hpp for K <= 7).  A step =
-    reset -> update(whole frame) -> chainback; the host-pointer boundary is part of the route (PCIe copies of 16 - 64 KiB each way
-    are inside the timed region: they ARE the product here), so this line is a latency figure, not the throughput headline."""
+    object with the reference's public state; update() runs ONE GPU launch that also chains the completed frame back
+    (vit_hip_update_host_lazy: symbols read from host-mapped memory, rows kept on the device, results polled), chainback() then
+    copies the bytes out.  A step = reset -> update(whole frame) -> chainback; the host-pointer boundary is part of the route (it IS
+    the product here), so this line is a latency figure, not the throughput headline."""
     import numpy as np
     from oracle import pyoracle
     from viterbidecodercpp_amd import (COMMON_CODES, ViterbiBranchTable, ViterbiDecoder_Config, ViterbiDecoder_Core, ViterbiDecoder_HIP,
@@ -561,7 +562,7 @@ def host_route(args):
         "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
         "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type}, ONE frame of {L} info bits through the header-level drop-in "
                                f"(ViterbiDecoder_HIP::update + ViterbiDecoder_Core::chainback, host-resident state), AWGN Eb/N0={args.ebn0} dB",
-                   "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": "one wavefront, lane == state (csrc/kernels_one.hpp)" if code.K <= 7 else "lds"},
+                   "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": "one wavefront, lane == state; update + the chainback behind it in ONE launch, rows kept on the device (csrc/kernels_one.hpp: one_frame_kernel)" if code.K <= 7 else "lds"},
         "update_ms": float(np.median(t_upd)) * 1e3, "chainback_ms": float(np.median(t_cb)) * 1e3,
         "ms_per_step_median": float(np.median(np.asarray(t_upd) + np.asarray(t_cb))) * 1e3,
         "ns_per_trellis_step_update": float(np.median(t_upd)) / S * 1e9,
