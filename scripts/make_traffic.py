@@ -25,12 +25,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILES = os.path.join(ROOT, "profiles")
 
 ENTRIES = [
-    ("Voyager|SOFT16|65536x8192|reg", "r5_k7_default_summary.md"),
+    ("Voyager|SOFT16|65536x8192|reg", "r6_k7_default_summary.md"),
     ("Voyager|SOFT16|16384x8192|lds", "r1_k7_lds_summary.md"),
     ("Cassini|SOFT16|1024x8192|lds2", "r1_k15_lds2_summary.md"),
-    ("CDMA IS-95A|SOFT16|65536x8192|reg", "r5_k9_summary.md"),
-    ("Cassini|SOFT16|4096x8192|lds2", "r5_k15_summary.md"),
-    ("Voyager|HARD8|32768x8192|reg", "r5_hard8_summary.md"),
+    ("CDMA IS-95A|SOFT16|65536x8192|reg", "r6_k9_summary.md"),
+    ("Cassini|SOFT16|4096x8192|lds2", "r6_k15_summary.md"),
+    ("Voyager|HARD8|32768x8192|reg", "r6_hard8_summary.md"),
 ]
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_<tag>/ (scripts/profile.sh) into profiles/<tag>_summary.md + profiles/<tag>_kernel_stats.csv and
-update profiles/traffic.json (read by bench.py for roofline.traffic).
+name the entry of profiles/traffic.json it feeds (scripts/make_traffic.py writes that file from the summaries).
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KiB (x1024); on gfx950
 FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced streaming reads, so the read side is doubled
@@ -134,18 +134,6 @@ open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 
 if key and traffic:
-    tpath = os.path.join(dst, "traffic.json")
-    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    upd = [k for k in traffic if "update_kernel" in k]
-    cb = [k for k in traffic if "chainback_kernel" in k or "chainback_alt_kernel" in k]
-    def valu(k):
-        v = counters[k].get("SQ_INSTS_VALU")
-        return sum(v) / len(v) if v else None
-
-    tj[key] = {"source": f"profiles/{tag}_summary.md",
-               "update_kernel_hbm_bytes_per_launch": traffic[upd[0]]["total"] if upd else None,
-               "chainback_kernel_hbm_bytes_per_launch": traffic[cb[0]]["total"] if cb else None,
-               "update_kernel_valu_insts_per_launch": valu(upd[0]) if upd else None,
-               "chainback_kernel_valu_insts_per_launch": valu(cb[0]) if cb else None,
-               "detail": traffic}
-    json.dump(tj, open(tpath, "w"), indent=1)
+    # profiles/traffic.json has ONE writer, scripts/make_traffic.py, which derives every entry from the summary it names: register the
+    # pair there (ENTRIES) and regenerate
+    print(f"\nnext: add (\"{key}\", \"{tag}_summary.md\") to ENTRIES in scripts/make_traffic.py and run it")
