@@ -76,8 +76,8 @@ extern "C" {
                                (vit_hip_precompile: no compiler on the serving host) or vit_hip_set_plan(h, PLAN_REG) compiles
                                an instantiation with hipcc on first use (10-40 s, cached on disk: VIT_HIP_CACHE_DIR)   */
 #define VIT_HIP_PLAN_LDS2 3 /* packed frame pair per workgroup, 16 states per thread, four trellis steps per barrier, u32
-                               metrics updated in place in LDS (K = 10..16, R <= 6, any polynomials; K = 10 at half
-                               occupancy of its wavefront)                                                              */
+                               metrics updated in place in LDS (K = 10..16, R <= 6, any polynomials; K = 10: two frame
+                               pairs per wavefront)                                                              */
 
 typedef struct vit_hip_decoder* vit_hip_handle;
 typedef void* vit_hip_stream_t;

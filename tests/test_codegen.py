@@ -15,15 +15,48 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 
 
+def _sources_digest():
+    """every file a kernel translation unit can see, and the compiler: the key of the compile cache below"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(f.encode() + b"\0" + open(f, "rb").read())
+    h.update(subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.encode())
+    return h.hexdigest()
+
+
+_DIGEST = None
+
+
 def _compile(src, defines, tmp_path):
+    """hipcc -S of one translation unit, with its resource remarks.  A compile takes 40 - 100 s and the sources rarely change between
+    two runs of the CPU suite: the assembly and the remarks are kept under csrc/build/codegen_cache/ (git-ignored), keyed by the
+    command line and a digest of every source file and of the compiler's version -- any edit compiles afresh."""
+    import hashlib
+    global _DIGEST
+    if _DIGEST is None:
+        _DIGEST = _sources_digest()
     out = tmp_path / "k.s"
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
            "-Rpass-analysis=kernel-resource-usage", "-o", str(out), src] + defines
-    p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
+    cache = os.path.join(CSRC, "build", "codegen_cache")
+    key = hashlib.sha256((_DIGEST + "\0" + "\0".join(cmd[:-len(defines) - 3] + [src] + defines)).encode()).hexdigest()[:32]
+    c_asm, c_err = os.path.join(cache, key + ".s"), os.path.join(cache, key + ".stderr")
+    if os.path.exists(c_asm) and os.path.exists(c_err) and not os.environ.get("VIT_TEST_NO_CODEGEN_CACHE"):
+        stderr = open(c_err).read()
+        out.write_text(open(c_asm).read())
+    else:
+        p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        stderr = p.stderr
+        os.makedirs(cache, exist_ok=True)
+        shutil.copyfile(str(out), c_asm + ".tmp")
+        os.replace(c_asm + ".tmp", c_asm)
+        open(c_err, "w").write(stderr)
     usage = {}
     name = None
-    for line in p.stderr.splitlines():
+    for line in stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)

@@ -214,8 +214,12 @@ struct Lds2Geom {
     // K = 15: 512 threads and 72 KiB of LDS per workgroup, so that TWO workgroups share a CU (4 waves per SIMD, 128 VGPRs);
     // K = 16: 1024 threads and 136 KiB, one workgroup per CU -- what the in-place update makes possible at all
     static constexpr int MINW = K >= 15 ? 4 : 2;
+    // frame pairs per workgroup.  K = 10 has 32 group slots: its one wavefront decodes TWO frame pairs, lanes 0 - 31 the first and lanes
+    // 32 - 63 the second, each half with its own tables, control words and metric buffer (round 5: the upper half mirrored the lower one
+    // through every load, butterfly and store -- half the vector unit idle, half of K = 11's rate per state update)
+    static constexpr int PPW = TG < 64 ? 2 : 1;
     static constexpr size_t tab_bytes = (size_t)2 * BLK * GPT * 64 * 8;
-    static constexpr size_t smem_bytes = tab_bytes + 32 * 4 + (size_t)N * 4;
+    static constexpr size_t smem_bytes = (size_t)PPW * (tab_bytes + 32 * 4 + (size_t)N * 4);
     static_assert(TG >= 32 && T <= 1024, "PLAN_LDS2 serves K = 10..16");
 };
 
@@ -238,17 +242,22 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     constexpr u32 STEP_TAB = (u32)GPT * 512u;              // bytes of one step's tables (group-A table, group-B table)
     constexpr u32 SET_TAB = (u32)BLK * STEP_TAB;           // bytes of one table set (the four steps of a block)
     extern __shared__ __attribute__((aligned(16))) u32 lds2_smem[];
+    constexpr int PPW = GM::PPW;                               // frame pairs per workgroup (2 at K = 10: one per half of the wavefront)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 half = PPW == 2 ? (u32)lane >> 5 : 0u;           // which of the workgroup's pairs this lane works for
+    const int ls = PPW == 2 ? (lane & 31) : tid;               // the lane's index among its pair's thread slots ...
+    constexpr int LT = PPW == 2 ? 32 : T;                      // ... of which there are this many
+    // layout: [tables of pair 0 | tables of pair 1][control words 0 | 1][metrics 0 | 1] -- everything per pair at `half` strides
     // tables first: their byte offsets (< 8 KiB) fit instruction offsets and 16-bit halves of a register
-    uint2* const etab = (uint2*)lds2_smem;                     // [2 sets][BLK][GPT][64] {E, max_error - E}
-    u32* const wmin = (u32*)((char*)lds2_smem + GM::tab_bytes); // [16]
+    uint2* const etab = (uint2*)((char*)lds2_smem + half * (u32)GM::tab_bytes);   // [2 sets][BLK][GPT][64] {E, max_error - E}
+    u32* const wmin = (u32*)((char*)lds2_smem + (size_t)PPW * GM::tab_bytes + half * 128u); // [16]
     u32* const flag = wmin + 16;                               // [0] careful routine wanted for the next block; [2] scratch; [4] arrivals
-    u32* const arrive = flag + 4;                              // wavefronts that have loaded their block's metrics, running total
+    u32* const arrive = (u32*)((char*)lds2_smem + (size_t)PPW * GM::tab_bytes) + 16 + 4;   // wavefronts that have loaded their block's metrics, running total (one counter per workgroup)
     uint64_t* const rs_acc = (uint64_t*)(flag + 8);            // [2] sum of subtracted minima, frame A / B (thread 0 only)
     u32* const sig = flag + 12;                                // [4] careful blocks: thread 0's per-stage "renormalise" word (slow_block)
     u32 careful_seq = 0;                                       // careful stages run so far: the same count in every wavefront
-    u32* const met = flag + 16;                                // [N], 16-byte aligned
+    u32* const met = (u32*)((char*)lds2_smem + (size_t)PPW * (GM::tab_bytes + 128u) + half * (u32)(N * 4));   // [N], 16-byte aligned
 
-    const int tid = threadIdx.x, lane = tid & 63;
     const int gid = tid & (GM::TG - 1);          // the thread's group slot (== tid except at K = 10, where lanes 32 - 63 mirror 0 - 31)
     // the wavefront's index, pinned uniform: everything derived from it (which table it builds, whether it builds one at all)
     // is then scalar control flow and scalar data, not exec-mask branches over vector compares
@@ -257,7 +266,10 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // branch (tid == 0 ...) and merges the copies in a phi that counts as divergent -- and with it the block loop's counter,
     // its table-set bit and every branch on them (vector compares, exec-mask branches, loop counters in VGPRs)
     const u32 t_begin = (u32)__builtin_amdgcn_readfirstlane((int)a.t_begin), t_end = (u32)__builtin_amdgcn_readfirstlane((int)a.t_end);
-    const u32 pair = blockIdx.x;
+    // (the second pair of the last workgroup may not exist: its lanes then decode the last pair again -- the same values to the same
+    // addresses, like the mirrored half of round 5 -- so that no path needs a lane predicate)
+    const u32 npairs = (a.frames + 1u) / 2u;
+    const u32 pair = PPW == 2 ? (blockIdx.x * 2u + half < npairs ? blockIdx.x * 2u + half : npairs - 1u) : blockIdx.x;
     const u32 fA = 2 * pair;
     const bool validB = fA + 1 < a.frames;
     const u32 fB = validB ? fA + 1 : fA;
@@ -284,7 +296,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 constexpr u32 r0 = ((h >> PB) << (PB + 1)) | (h & ((1 << PB) - 1));
                 const u32 lower = lds2_state_of(C - 1, r0, (u32)gid, SBITS);   // top bit clear: butterfly index < H
                 // byte offset from lds2_smem of this butterfly's entry in table set 0 (set 1: + SET_TAB, an instruction offset)
-                const u32 off = (u32)C * STEP_TAB + lds2_tab_index((u32)a.pattern[lower] & 63u, a.idx_f[C], a.idx_t[C]) * 8u;
+                const u32 off = half * (u32)GM::tab_bytes + (u32)C * STEP_TAB + lds2_tab_index((u32)a.pattern[lower] & 63u, a.idx_f[C], a.idx_t[C]) * 8u;
                 pk |= off << (16 * decltype(ec)::value);
             });
             prow2[C][h2] = pk;
@@ -293,7 +305,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 
     // ---- reset (viterbi_decoder_core.h:202-211), or resume from the metrics an earlier call left ----
     if (a.metrics_in) {
-        for (int s = tid; s < N; s += T) {
+        for (int s = ls; s < N; s += LT) {
             u32 lo, hi;
             if (SHIFT) {
                 lo = (u32)((const uint8_t*)a.metrics_in)[(size_t)fA * N + s] << 8;
@@ -307,13 +319,13 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     } else {
         const u32 sA = a.start_state ? (a.start_state[fA] & (u32)(N - 1)) : 0u;
         const u32 sB = a.start_state ? (a.start_state[fB] & (u32)(N - 1)) : 0u;
-        for (int s = tid; s < N; s += T) {
+        for (int s = ls; s < N; s += LT) {
             const u32 lo = ((u32)s == sA) ? a.cfg.init_start : a.cfg.init_non_start;
             const u32 hi = ((u32)s == sB) ? a.cfg.init_start : a.cfg.init_non_start;
             met[lds2_sw((u32)s, (u32)N)] = (lo | (hi << 16)) ^ BIAS2;
         }
     }
-    if (tid < 16) flag[tid] = 0;              // flags and the two 64-bit renormalisation sums
+    if (ls < 16) flag[ls] = 0;                // flags and the two 64-bit renormalisation sums
 
     // ---- branch-metric table builder: lane p makes entry p of the tables of one step ----
     const uint8_t* symA = a.symbols + (size_t)fA * a.sym_frame_stride_bytes;
@@ -360,7 +372,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #ifndef VIT_L2_SCALAR_BUILD
 #define VIT_L2_SCALAR_BUILD 0
 #endif
-    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB, bool valid = true) __attribute__((always_inline)) {
+    auto build_table = [&](uint2* tab, const u32 (&y)[6], u32 pos, u32 posB, bool valid = true, u32 pat = 0u) __attribute__((always_inline)) {
         u32 e = 0;
         if constexpr (VIT_L2_SCALAR_BUILD != 0) {
             // EXPERIMENT (-DVIT_L2_SCALAR_BUILD=1): the symbols are wave-uniform, so what does not depend on the lane runs on the scalar
@@ -407,6 +419,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         // 120-register cap sends to scratch, reloaded behind a full vmcnt(0) right in front of the build
         u32 ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         l2_opaque(ln);
+        if constexpr (PPW == 2) ln = pat;       // the pass form with 32 lanes per pair: the lane's pattern is not its lane number's low bits (R = 6)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i < R) {
@@ -474,22 +487,29 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // (K = 12, two wavefronts of two steps each, does the same with E >= 32: one pass up to R = 5)
     constexpr bool PASSES = NW <= 2 && RT == 0;                     // K = 10, 11, 12 and (two groups per thread: a table B per step) 13
     constexpr int SPW = BLK / (NW <= 2 ? NW : 1);                   // steps a wavefront serves: 4, 2
-    constexpr int LGE_MIN = SPW == 4 ? 4 : 5;                       // 64 / SPW lanes per step at most
+    constexpr int LGE_MIN = PPW == 2 ? 3 : SPW == 4 ? 4 : 5;        // 64 / SPW lanes per step at most (two pairs per wavefront: 32 / SPW)
     const int lgE = R <= LGE_MIN ? LGE_MIN : R;                     // wave-uniform
-    const int n_pass = PASSES ? SPW >> (6 - lgE) : 0;               // 1, 2, 4
+    constexpr int LGLW = PPW == 2 ? 5 : 6;                          // log2 of the lanes that build one pair's tables
+    const int n_pass = PASSES ? (lgE <= LGLW ? SPW >> (LGLW - lgE) : SPW << (lgE - LGLW)) : 0;   // 1, 2, 4 (two pairs per wavefront: 2, 4, 8)
     // the block step this lane serves in pass j is pass_step(j) = j * (64 / E) + lane / E; where its entry goes: pass_pos(j) -- kept in
     // a register for pass 0 (the only pass of every code with R <= 4), formed again in the later passes of an R = 5, 6 code (four
     // more loop-invariant registers send the kernel to scratch, with a reload behind a full vmcnt(0) in every block)
+    // entry e = j * (lanes per pair) + lane index of the wavefront's SPW * E entries: step e / E, pattern e % E
     u32 pass_c0 = (u32)lane >> lgE;
     auto pass_step = [&](int j) __attribute__((always_inline)) -> u32 {
+        if constexpr (PPW == 2) return ((((u32)j << LGLW) + (u32)ls) >> lgE) & (u32)(BLK - 1);
         return ((u32)(wave * SPW) + ((u32)j << (6 - lgE)) + pass_c0) & (u32)(BLK - 1);
+    };
+    auto pass_pat = [&](int j) __attribute__((always_inline)) -> u32 {
+        if constexpr (PPW == 2) return (((u32)j << LGLW) + (u32)ls) & ((1u << lgE) - 1u);
+        return (u32)lane & ((1u << lgE) - 1u);
     };
     auto pass_pos = [&](int j) __attribute__((always_inline)) -> u32 {
         const u32 cc = pass_step(j);
         const u32 f = cc == 0 ? a.idx_f[0] : cc == 1 ? a.idx_f[1] : cc == 2 ? a.idx_f[2] : a.idx_f[3];
         const u32 t = cc == 0 ? a.idx_t[0] : cc == 1 ? a.idx_t[1] : cc == 2 ? a.idx_t[2] : a.idx_t[3];
         // entry of the lane's pattern inside the table of ITS step (tables of a set: BLK x GPT x 64 entries)
-        return cc * (u32)(GPT * 64) + lds2_tab_index((u32)lane & ((1u << lgE) - 1u), f, t);
+        return cc * (u32)(GPT * 64) + lds2_tab_index(pass_pat(j), f, t);
     };
     // ... and, XORed onto it, where the same sum goes in the step's table B (two groups per thread): index(p ^ xb) = index(p) ^ index(xb)
     auto pass_xorB = [&](int j) __attribute__((always_inline)) -> u32 {
@@ -555,7 +575,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         if constexpr (PASSES) {
             {
                 const u32 ts = t0 + pass_step(0);
-                build_table(etab + (size_t)(set * BLK) * GPT * 64, yland[0], tabpos[0], tabpos[0] ^ tabxorB[0], ts < t_end && ts >= t_begin);
+                build_table(etab + (size_t)(set * BLK) * GPT * 64, yland[0], tabpos[0], tabpos[0] ^ tabxorB[0], ts < t_end && ts >= t_begin, pass_pat(0));
             }
             // R = 5, 6: one or three more passes, each fetching its symbols on the spot (the other wavefronts of the SIMD cover the
             // wait; symbols of four passes held a block ahead are 18 registers the 120-register kernel does not have) -- a real loop,
@@ -569,7 +589,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 u32 y[6] = {0, 0, 0, 0, 0, 0};
                 load_syms(tc, y);
                 const u32 pj = pass_pos(j);
-                build_table(etab + (size_t)(set * BLK) * GPT * 64, y, pj, GPT == 2 ? pj ^ pass_xorB(j) : 0u, valid);
+                build_table(etab + (size_t)(set * BLK) * GPT * 64, y, pj, GPT == 2 ? pj ^ pass_xorB(j) : 0u, valid, pass_pat(j));
             }
             return;
         }
@@ -603,8 +623,14 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     tables_load(tb0 + BLK);
     tables_commit();
     __syncthreads();
-    if (tid == 0) flag[0] = predict(met[0], tb0, 0);
+    if (ls == 0) flag[0] = predict(met[0], tb0, 0);
     __syncthreads();
+    // "the next block runs the careful routine": block-uniform; with two pairs per wavefront, if EITHER pair's prediction says so
+    auto read_careful = [&]() __attribute__((always_inline)) -> u32 {
+        const u32 v = flag[0];
+        if constexpr (PPW == 2) return (u32)__builtin_amdgcn_readlane((int)v, 0) | (u32)__builtin_amdgcn_readlane((int)v, 32);
+        return (u32)__builtin_amdgcn_readfirstlane((int)v);
+    };
 
     u32* const ws_pair = a.ws + (size_t)pair * a.ws_pair_stride;
 
@@ -665,7 +691,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     // instruction): left to itself hipcc materialises the 32 + 8 derived addresses as loop-invariant registers and spills them
     // (236 bytes of scratch, ~50 reloads per block); re-forming them from the thread index in every block, as round 2 did,
     // cost 27 VALU per block.
-    constexpr u32 MET_OFF = (u32)GM::tab_bytes + 32u * 4u;                 // byte offset of met[] inside lds2_smem
+    const u32 MET_OFF = (u32)PPW * ((u32)GM::tab_bytes + 32u * 4u) + half * (u32)(N * 4);   // byte offset of met[] inside lds2_smem (a constant but with two pairs per wavefront)
     const u32 ld_off = MET_OFF + 4u * lds2_sw((u32)gid, (u32)N);     // relative to lds2_smem
     // the compile-time-rate instantiation has the registers for all four store offsets; the others carry one and form the rest
     // with a v_xor each
@@ -848,14 +874,14 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             for (int i = 0; i < 16; ++i) mn = l2_min_s(mn, mB[i]);
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));
+        for (int off = PPW == 2 ? 16 : 32; off >= 1; off >>= 1) mn = l2_min_s(mn, (u32)__shfl_xor((int)mn, off));   // (two pairs per wavefront: each half on its own)
         // two sets of per-wavefront minima, used in turn (up to eight wavefronts: K <= 15): the barrier below is then the only one of a
         // reduction -- the next reduction writes the other set, and the one after it cannot start before everybody has passed
         // the next one's barrier, i.e. has long read this set
         constexpr bool WMIN2 = NW <= 8;
         u32* const wm = wmin + (WMIN2 ? (renorm_count & 1u) * 8u : 0u);
         renorm_count += 1u;
-        if (lane == 0) wm[wave] = mn;
+        if ((PPW == 2 ? ls : lane) == 0) wm[wave] = mn;
         __syncthreads();
         for (int w = 0; w < NW; ++w) mn = l2_min_s(mn, wm[w]);
         const u32 sub = (mn ^ BIAS2) & msk;   // true (unbiased) minimum of each frame that renormalises
@@ -865,7 +891,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) mB[i] = l2_sub(mB[i], sub);
         }
-        if (tid == 0) {                       // update()'s return value: kept in LDS, not in four VGPRs of every thread
+        if (ls == 0) {                        // update()'s return value: kept in LDS, not in four VGPRs of every thread
             rs_acc[0] += (uint64_t)((sub & 0xFFFFu) >> SHIFT);
             rs_acc[1] += (uint64_t)((sub >> 16) >> SHIFT);
         }
@@ -908,15 +934,15 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 // its word sooner, changed nothing -- 59.4: what is left of SOFT8's distance to HARD8's 50.4 ms is the reduction and
                 // the 32 subtractions themselves, about once per block.)
                 careful_seq += 1u;
-                if (tid == 0) {
+                if (ls == 0) {
                     const u32 nb2 = (l2_sub_sat_s(THRM1B2, mA[0]) | FORCE) & BIAS2;
                     __hip_atomic_store(&sig[C], (careful_seq << 2) | ((nb2 >> 15) & 1u) | ((nb2 >> 30) & 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 u32 sv;
                 while (((sv = __hip_atomic_load(&sig[C], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != careful_seq) __builtin_amdgcn_s_sleep(1);
-                sv = (u32)__builtin_amdgcn_readfirstlane((int)sv);                    // block-uniform: scalar branch
-                const u32 need = ((sv & 1u) << 15) | ((sv & 2u) << 30);
-                if (need != 0) renormalise(need);
+                if constexpr (PPW == 1) sv = (u32)__builtin_amdgcn_readfirstlane((int)sv);   // block-uniform: scalar branch
+                const u32 need = ((sv & 1u) << 15) | ((sv & 2u) << 30);               // (two pairs per wavefront: per half)
+                if (PPW == 2 ? __builtin_amdgcn_ballot_w64(need != 0) != 0 : need != 0) renormalise(need);
                 if (C == nst - 1) {
                     if (C == BLK - 1) {
                         store_metrics();
@@ -930,9 +956,9 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
                 }
             }
         });
-        if (tid == 0) flag[0] = nst == BLK ? predict(mA[0], t0 + BLK, set ^ 1) : 1u;
+        if (ls == 0) flag[0] = nst == BLK ? predict(mA[0], t0 + BLK, set ^ 1) : 1u;
         __syncthreads();                       // B2
-        return (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);
+        return read_careful();
     };
     // the fast version: four stages back to back between the two barriers.  Returns the prediction for the next block.
     auto fast_block = [&](int set, u32 t0, u32 arrive_target) __attribute__((always_inline)) -> u32 {
@@ -951,14 +977,15 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         tables_load(t0 + 2 * BLK);             // the symbols of the block after next: in flight across the barrier
         store_metrics();
-        if (tid == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);
+        if (ls == 0) flag[0] = predict(mA[0], t0 + BLK, set ^ 1);
         __syncthreads();                       // B2
         tables_commit();
-        const u32 pred = (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);   // uniform by construction, and carried as a dword (a
+        const u32 pred = read_careful();                                       // uniform by construction, and carried as a dword (a
                                                                               // loop-carried bool becomes a lane mask): the block loop's control flow stays scalar
         // renormalise when new_metric[0] >= threshold after the block's last step: block-uniform
-        const u32 need = (u32)__builtin_amdgcn_readfirstlane((int)((l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2));   // sign bits: frame A / frame B
-        if (need != 0) {
+        u32 need = (l2_sub_sat_s(THRM1B2, met[0]) | FORCE) & BIAS2;            // sign bits: frame A / frame B
+        if constexpr (PPW == 1) need = (u32)__builtin_amdgcn_readfirstlane((int)need);
+        if (PPW == 2 ? __builtin_amdgcn_ballot_w64(need != 0) != 0 : need != 0) {
             __syncthreads();                   // everybody has read met[0] and flag[0] before they can change
             renormalise(need);
             store_metrics();
@@ -970,7 +997,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     u32 t0 = tb0;
     u32 arrivals_wanted = (u32)NW;            // value of *arrive once every wavefront has loaded the current block's metrics
     int set = 0;                              // table set that holds block t0
-    u32 careful = (u32)__builtin_amdgcn_readfirstlane((int)flag[0]);
+    u32 careful = read_careful();
     while (t0 < t_end) {
         const u32 left = t_end - t0;
         const int nst = left < (u32)BLK ? (int)left : BLK;
@@ -996,9 +1023,9 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
     if (a.metrics_out) {
         // an opaque copy of the thread index: the addresses of this once-per-call write-out are functions of it, and formed in
         // front of the block loop (where hipcc hoists them to) they sit in registers the loop needs -- or in scratch
-        int s_first = tid;
+        int s_first = ls;
         asm volatile("" : "+v"(s_first));
-        for (int s = s_first; s < N; s += T) {
+        for (int s = s_first; s < N; s += LT) {
             const u32 v = met[lds2_sw((u32)s, (u32)N)] ^ BIAS2;
             if (SHIFT) {
                 ((uint8_t*)a.metrics_out)[(size_t)fA * N + s] = (uint8_t)((v & 0xFFFFu) >> 8);
@@ -1009,7 +1036,7 @@ __device__ __forceinline__ void lds2_update_body(Lds2UpdateArgs a) {
             }
         }
     }
-    if (a.renorm_sum && tid == 0) {
+    if (a.renorm_sum && ls == 0) {
         a.renorm_sum[fA] = rs_acc[0];
         if (validB) a.renorm_sum[fB] = rs_acc[1];
     }
@@ -1027,11 +1054,11 @@ template <int K, int SHIFT, int RT = 0>
 __global__ void __launch_bounds__(Lds2Geom<K>::T, Lds2Geom<K>::MINW) __attribute__((amdgpu_num_vgpr(60)))
 lds2_update_kernel_c120(Lds2UpdateArgs a) { lds2_update_body<K, SHIFT, RT>(a); }
 // the instantiation lds2_launch_update picks for (K, R): capped kernel or not, compile-time rate or not
-inline bool lds2_update_is_capped(int K) { return K == 10 || K == 11 || K == 14 || K == 15; }
+inline bool lds2_update_is_capped(int K) { return K == 11 || K == 14 || K == 15; }   // (K = 10: two pairs per wavefront, 12.4 KiB of LDS: three waves per SIMD, no cap needed)
 inline int lds2_update_rt(int K, int R) { return (K == 15 && R == 6) ? 6 : 0; }
 inline size_t lds2_smem_bytes(int K) {
     const size_t N = (size_t)1 << (K - 1), G = N / 16, GPT = G >= 256 ? 2 : 1;
-    return (size_t)2 * 4 * GPT * 64 * 8 + 32 * 4 + N * 4;                 // Lds2Geom<K>::smem_bytes
+    return (size_t)(K == 10 ? 2 : 1) * ((size_t)2 * 4 * GPT * 64 * 8 + 32 * 4 + N * 4);                 // Lds2Geom<K>::smem_bytes
 }
 // what one wave of the update / chainback kernel of (K, R) allocates: from the kernel descriptors (kernel_desc.hpp)
 inline bool lds2_kernel_resources(int K, int R, int shift, bool update, kd::KernelResources* out, unsigned* dyn_lds_bytes = nullptr) {
@@ -1178,7 +1205,7 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
     using GM = Lds2Geom<K>;
     void (*kern)(Lds2UpdateArgs) = nullptr;
     if constexpr (K == 15) kern = (a.R == 6) ? lds2_update_kernel_c120<K, SHIFT, 6> : lds2_update_kernel_c120<K, SHIFT, 0>;
-    else if constexpr (K == 10 || K == 11 || K == 14) kern = lds2_update_kernel_c120<K, SHIFT, 0>;
+    else if constexpr (K == 11 || K == 14) kern = lds2_update_kernel_c120<K, SHIFT, 0>;
     else kern = lds2_update_kernel<K, SHIFT, 0>;
     if (GM::smem_bytes > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1192,7 +1219,7 @@ int lds2_launch_update(const Lds2UpdateArgs& a, unsigned pairs, hipStream_t st) 
         fprintf(stderr, "lds2_update_kernel<%d>: %d threads, %zu B LDS per workgroup, %d workgroup(s) per CU\n", K, GM::T, GM::smem_bytes, nb);
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(pairs), dim3(GM::T), GM::smem_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((pairs + (unsigned)GM::PPW - 1u) / (unsigned)GM::PPW), dim3(GM::T), GM::smem_bytes, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
