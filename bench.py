@@ -540,10 +540,17 @@ def host_route(args):
     for _ in range(args.warmup):
         one()
     del t_upd[:], t_cb[:]
+    # the interpreter's cyclic collector runs on allocation counts: with torch imported a full collection takes ~40 ms and lands,
+    # deterministically, in the 186th timed step (one 1.4 ms young-generation pass in the 57th) -- 130 frame times charged to one
+    # frame.  It is the host's housekeeping, not the route's: collected once here, off inside the timed loop
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         acc, out = one()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     S = L + code.K - 1
     dt = {"SOFT16": pyoracle.SOFT16, "SOFT8": pyoracle.SOFT8, "HARD8": pyoracle.HARD8}[args.decode_type]
     ocfg = pyoracle.stock_config(dt, code.R)
@@ -565,6 +572,11 @@ def host_route(args):
                    "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": "one wavefront, lane == state; update + the chainback behind it in ONE launch, rows kept on the device (csrc/kernels_one.hpp: one_frame_kernel)" if code.K <= 7 else "lds"},
         "update_ms": float(np.median(t_upd)) * 1e3, "chainback_ms": float(np.median(t_cb)) * 1e3,
         "ms_per_step_median": float(np.median(np.asarray(t_upd) + np.asarray(t_cb))) * 1e3,
+        # the spread of the two calls themselves (a step's reset() and the loop around them are the rest of ms_per_step)
+        "update_ms_mean": float(np.mean(t_upd)) * 1e3, "update_ms_max": float(np.max(t_upd)) * 1e3,
+        "update_ms_p99": float(np.percentile(t_upd, 99)) * 1e3, "update_ms_series_head": [round(float(x) * 1e3, 4) for x in t_upd[:32]],
+        "slow_update_calls_over_2x_median": int(np.sum(np.asarray(t_upd) > 2 * np.median(t_upd))),
+        "slow_update_calls": [(int(i), round(float(t_upd[i]) * 1e3, 3)) for i in np.nonzero(np.asarray(t_upd) > 2 * np.median(t_upd))[0][:16]],
         "ns_per_trellis_step_update": float(np.median(t_upd)) / S * 1e9,
         # a dependent chain of S steps on one wavefront: the HBM roofline does not bound it; quoted for the record's shape only
         "roofline": {"bound": "hbm", "kernel": "single-frame update (latency route)", "achieved": frame_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,

@@ -1498,6 +1498,9 @@ int vit_hip_update_host_lazy(vit_hip_handle h, void* metrics_inout, const void* 
         __builtin_ia32_pause();
 #endif
     }
+    // let the runtime see that the launch has retired: polled completions never pass through it, and a queue it believes full of
+    // pending kernels is drained the hard way once in ~200 launches (two 38 ms calls in 400)
+    (void)hipStreamQuery(h->stream);
     memcpy(metrics_inout, hm + met_off, met_bytes);
     if (renorm_sum_out) memcpy(renorm_sum_out, hm + 64, 8);
     if (spec) { h->spec_valid = true; h->spec_bits = speculate_bits; h->spec_end = speculate_end_state; h->spec_off = out_off; }
