@@ -122,7 +122,8 @@ int main(int argc, char** argv) {
                 acc += shorty.take_unreported_renormalisation();
                 ok = ok && acc == acc_once && acc + e == err_once;
             } else {
-                shorty.reset();                                                     // the debt does NOT survive the reset:
+                shorty.reset();                                                     // the debt does NOT survive the reset ...
+                ok = ok && acc + shorty.last_dropped_renormalisation() == acc_once;   // ... but what was dropped stays readable
                 const uint64_t first = Decoder::template update<uint64_t>(shorty, symbols.data(), R);
                 (void)shorty.get_error();                                           // (run the queued step)
                 ok = ok && first + shorty.take_unreported_renormalisation() == 0;   // one step from reset renormalises nothing

@@ -148,7 +148,9 @@ def test_streaming_exact_return_mode_and_short_frames(oracle, decode_type):
             acc += short.take_unreported_renormalisation()
             assert acc == whole["renorm_sum"]
         else:
-            short.reset()                                   # the tail's sum is dropped, not carried into the next frame
+            short.reset()                                   # the tail's sum is dropped, not carried into the next frame ...
+            # ... but not silently: what reset() dropped stays readable, and with it the frame's total is the reference's
+            assert acc + short.last_dropped_renormalisation() == whole["renorm_sum"]
             first = ViterbiDecoder_HIP.update(short, flat[:code.R])
             short.get_error()
             assert first + short.take_unreported_renormalisation() == per_call[0]
