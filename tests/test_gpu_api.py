@@ -218,9 +218,13 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     # that were precompiled into the package at install time (tools/precompile.py: COMMON_SETS)
     from viterbidecodercpp_amd.tools.precompile import COMMON_SETS
     in_package = any((K, R, tuple(G)) == (k, r, g) for _, k, r, g in COMMON_SETS)
-    assert BatchDecoder(table, config).plan == (_lib.PLAN_REG if in_package else _lib.PLAN_LDS)
+    generic = 7 <= K <= 9 and 2 <= R <= 4           # ... or, for these (K, R), the package's GENERIC kernels (tests/test_gpu_generic.py)
+    auto = BatchDecoder(table, config)
+    assert auto.plan == (_lib.PLAN_REG if in_package or generic else _lib.PLAN_LDS)
+    assert ("GENERIC" in auto.plan_note) == (generic and not in_package), auto.plan_note
+    # asking for the register plan by name gets kernels specialised for the set (here: from the session's user cache)
     dec = check_batch_against_oracle(oracle, code, decode_type, 70, 384, 3.0, seed=K * R, plan=_lib.PLAN_REG)
-    assert dec.plan == _lib.PLAN_REG
+    assert dec.plan == _lib.PLAN_REG and "GENERIC" not in dec.plan_note, dec.plan_note
     # the run-time compiled code object's kernel descriptors are readable too (the pipeline's residency rules need them): from
     # the .hsaco in the cache directory
     upd, cb = dec.kernel_resources(_lib.KERNEL_UPDATE), dec.kernel_resources(_lib.KERNEL_CHAINBACK)
@@ -262,7 +266,7 @@ def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tm
     lib = _lib.load()
     monkeypatch.setenv("VIT_HIP_HIPCC", "/nonexistent/hipcc")
     monkeypatch.setenv("VIT_HIP_CACHE_DIR", str(tmp_path))
-    code = Code("custom", 7, 2, (0o147, 0o135))
+    code = Code("custom", 6, 2, (0o73, 0o45))                        # (K = 6: no generic kernels to fall back on)
     pc, table, config = make_table_config(code, "SOFT16")
     dec = BatchDecoder(table, config)
     assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.ERR_UNSUPPORTED
@@ -270,6 +274,13 @@ def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tm
     assert b"hipcc" in msg, msg
     dec._handle.refresh()
     assert dec.plan == _lib.PLAN_LDS                                  # still usable on the LDS plan
+    # K = 7..9, R <= 4: the handle already runs the package's GENERIC kernels; the failed attempt at specialised ones leaves them in place
+    pc, table, config = make_table_config(Code("custom", 7, 2, (0o147, 0o135)), "SOFT16")
+    dec = BatchDecoder(table, config)
+    assert dec.plan == _lib.PLAN_REG and "GENERIC" in dec.plan_note
+    assert lib.vit_hip_set_plan(dec._handle._h, _lib.PLAN_REG) == _lib.OK
+    dec._handle.refresh()
+    assert dec.plan == _lib.PLAN_REG and "GENERIC" in dec.plan_note
 
 
 def test_precompiled_package_cache_serves_plan_reg_without_a_compiler(oracle, monkeypatch, tmp_path):
@@ -292,8 +303,12 @@ def test_precompiled_package_cache_serves_plan_reg_without_a_compiler(oracle, mo
         assert dec.plan == _lib.PLAN_REG, dec.plan_note
         assert "package cache" in dec.plan_note and "/precompiled/reg_K" in dec.plan_note, dec.plan_note
     assert not any(f.endswith(".hsaco") for f in os.listdir(tmp_path))          # nothing was compiled
-    # a set that was NOT precompiled stays on the compatibility plan, and asking for the register plan is a clean error here
+    # a set that was NOT precompiled runs the package's GENERIC kernels where (K, R) has them (K = 7..9, R <= 4: tests/test_gpu_generic.py)
+    # and stays on the compatibility plan where not
     pc, table, config = make_table_config(Code("custom", 7, 2, (0o147, 0o135)), "SOFT16")
+    d = BatchDecoder(table, config)
+    assert d.plan == _lib.PLAN_REG and "GENERIC" in d.plan_note, d.plan_note
+    pc, table, config = make_table_config(Code("custom", 6, 2, (0o73, 0o45)), "SOFT16")
     assert BatchDecoder(table, config).plan == _lib.PLAN_LDS
     # rate: the headline batch size
     code = Code("802.11 K7", 7, 2, (0o171, 0o133))
@@ -374,7 +389,7 @@ def test_symbol_buffers_at_odd_offsets(oracle, code_id, decode_type, plans):
     ((11, 2, (0o3345, 0o3613)), "SOFT16", 40, 128, (2, 1, 1)),    # K = 11: the same
     ((13, 2, (0o10533, 0o17661)), "SOFT16", 24, 128, (2, 1, 1)),  # K = 13 (144 registers allocated, three waves per SIMD by LDS: 3 x 144 + 24 of 512): overlapped too -- the descriptor rule; 8192 x 4096: 16.4 -> 16.0 ms per batch
     ((10, 2, (0o1167, 0o1545)), "SOFT16", 200, 128, (2, 1, 1)),   # K = 10 (PLAN_LDS2 since round 5, capped at 120 registers): overlapped
-    ((8, 3, (0o367, 0o331, 0o225)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 8, R = 3 (PLAN_LDS as long as nobody asks for the run-time compiled register plan): back to back
+    ((6, 3, (0o65, 0o57, 0o75)), "SOFT16", 200, 128, (2, 1, 0)),   # K = 6, R = 3 (PLAN_LDS as long as nobody asks for the run-time compiled register plan): back to back
     (5, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 2: two 240-register update waves leave room for the LDS-streaming chainback
     (6, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 9, R = 4: 224 registers with the sub-chunk branch-metric fetch (368 before: sub-batches), 8 KiB of LDS per wave
     (3, "SOFT16", 40000, 64, (2, 1, 1)),     # K = 7, R = 3 (LTE): update capped at 240 registers: 2 x 240 + 32

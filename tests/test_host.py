@@ -184,13 +184,17 @@ def test_precompile_writes_a_code_object_without_a_gpu(tmp_path):
     G = (C.c_uint32 * 6)(0o1167, 0o1545)
     assert lib.vit_hip_precompile(10, 2, G, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_precompile(7, 2, G, 4, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
+    # all polynomials zero names the GENERIC kernels of (K, R) (polynomials read at run time): K = 7..9 with R = 2..4 only
+    Z = (C.c_uint32 * 6)()
+    assert lib.vit_hip_precompile(6, 2, Z, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_precompile(7, 5, Z, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     # the package cache build() fills: every common set, both widths, compiled from the CURRENT kernel sources
     pkg = os.path.join(ROOT, "viterbidecodercpp_amd", "precompiled")
     have = set(os.listdir(pkg)) if os.path.isdir(pkg) else set()
     suffix = name.rsplit("_", 1)[1]
     for _, K, R, Gs in precompile.COMMON_SETS:
         for w in (8, 16):
-            g = [x | 1 | (1 << (K - 1)) for x in Gs] + [0] * (6 - R)
+            g = [x | 1 | (1 << (K - 1)) if any(Gs) else 0 for x in Gs] + [0] * (6 - R)     # (all zero: the GENERIC kernels of (K, R))
             want = f"reg_K{K}R{R}_" + "_".join(str(x) for x in g) + f"_s{w}_gfx950_{suffix}"
             assert want in have, f"{want} missing from {pkg}: run build()"
 

@@ -125,6 +125,15 @@ struct RegSpec {
     static constexpr int NPROW = (NPL + NPH) <= 8 ? (NPL + NPH <= 4 ? (NPL + NPH <= 2 ? NPL + NPH : 4) : 8) : 16;
     static_assert(!SPLIT || NPL + NPH <= 16, "split tables: at most 8 + 8 entries");
     static constexpr int SB = K - 1;              // state bits
+    // GENERIC (all polynomials zero in the template arguments): ONE code object for EVERY polynomial set of this (K, R).  The
+    // reference takes G at run time (viterbi_branch_table.h:34-55); the specialised kernels bake pat(r) into register choices and
+    // ds_read offsets, which needs a compiler per set.  Here each butterfly h of a step fetches ITS OWN {E, max_error - E} pair from
+    // the ring through a run-time address: the kernel's prologue forms, from the polynomials in its arguments, the table
+    // [layout step][lane group q][butterfly h] of ring byte offsets ((pat_reg ^ pat_lane) << 7) in LDS; a step reads its row two
+    // steps ahead (two ds_read_b128 at K = 7), ORs the lane's pair offset in (NREG / 2 two-pass-free v_or_b32) and issues NREG / 2
+    // ds_read_b64 instead of 2^R.  The producer writes entry P at index P (bm_index is the identity for zero polynomials).
+    static constexpr bool GENERIC = G0 == 0 && G1 == 0 && G2 == 0 && G3 == 0 && G4 == 0 && G5 == 0;
+    static_assert(!GENERIC || (LANE_BITS_ == 2 && R_ <= 4), "generic kernels: the LDS-ring geometries (K >= 7) with whole patterns (R <= 4)");
     // LANE_BITS = 2: two state-slot bits live in the lane index (lane bits 4 and 5), 16 frame pairs per wave;
     // LANE_BITS = 0 (small K): every state of a frame pair lives in ONE lane's registers, 64 frame pairs per wave
     static constexpr int LANE_BITS = LANE_BITS_;
@@ -155,6 +164,7 @@ struct RegSpec {
     // does any butterfly carry pattern p?  pat() is linear, its image a subspace: a polynomial set that repeats a polynomial (DAB:
     // 109, 79, 83, 109) reaches only half of the 2^R patterns, and the producer makes no entry for the others
     static constexpr bool pat_used(u32 p) {
+        if (GENERIC) return true;                 // the polynomials arrive at run time: every pattern may occur
         for (u32 v = 0; v <= SMASK; ++v)
             if (pat(v) == p) return true;
         return false;
@@ -315,11 +325,13 @@ struct RegChunk {
         return part == 0 ? p : part == 1 ? (p & (u32)(SP::NPL - 1)) : (p >> SP::RL);
     }
     static constexpr int first(int PH, int h, int part = 0) {
+        if (SP::GENERIC) return h;          // polynomials at run time: nothing is known to repeat, every butterfly fetches its own pair
         for (int k = h / CS * CS; k < h; ++k)
             if (pat_part(PH, k, part) == pat_part(PH, h, part)) return k;
         return h;
     }
     static constexpr int slot(int PH, int h, int part = 0) {
+        if (SP::GENERIC) return h % CS;
         const int f = first(PH, h, part);
         int n = 0;
         for (int k = h / CS * CS; k < f; ++k)
@@ -346,6 +358,7 @@ struct RegUpdateArgs {
     u32 frames;
     u32 t_begin, t_end;     // trellis steps [t_begin, t_end) of every frame; the symbol chunk starts at step t_begin
     DevConfig cfg;
+    u32 gen_G[6];           // the code's polynomials: read by the GENERIC kernels only (RegSpec::GENERIC)
 #ifdef VIT_HIP_CLOCK_STAMPS
     uint64_t* stamps;
 #endif
@@ -401,6 +414,10 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     constexpr int SBY = SHIFT ? 1 : 2;   // sizeof(soft_t)
     constexpr int BPS = R * SBY;         // symbol bytes per trellis step per frame
     constexpr int NP = 1 << R;
+    // GENERIC (RegSpec): polynomials at run time -- every butterfly of a step fetches its own pair: NH "patterns" per step
+    constexpr bool GENERIC = SP::GENERIC;
+    constexpr int NH = NREG / 2;
+    constexpr int NPF = GENERIC ? NH : NP;         // {E, max_error - E} pairs a lane holds per step
     // LDSBM: the 4 q-lanes of a frame pair share the branch-metric work through LDS.  In every group of 4 trellis steps
     // lane (q, g) loads only the symbols of step 4J+q of its pair, computes that step's 2^R sums E[p] / max_error - E[p]
     // ONCE (with the unswapped high / low) and parks them in an LDS ring; every step each lane then fetches
@@ -417,7 +434,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // K = 9, R = 3, 4: branch metrics fetched per sub-chunk of four butterflies instead of per step (RegChunk).  Their LDS ring
     // holds ONE group of four steps (8 KiB per wave at R = 4, so that eight update waves and two 40 KiB chainback workgroups share
     // a CU): the next group is produced INSIDE a group's last step, right behind the last fetch of the old one
-    constexpr bool BMCHUNK = LDSBM && !SP::X3 && ((NREG >= 64 && NP >= 8) || (NREG >= 32 && NP >= 16));
+    constexpr bool BMCHUNK = LDSBM && !SP::X3 && ((NREG >= 64 && NP >= 8) || (NREG >= 32 && NP >= 16) || (SP::GENERIC && NREG >= 32));
     using RC = RegChunk<SP>;
     // R = 5, 6: the pattern is split into a low and a high part with a table each (RegSpec::SPLIT): NPROW entries per step
     constexpr bool SPLIT = SP::SPLIT;
@@ -434,6 +451,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     static_assert(!LDSBM || (BPS <= 12 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
     constexpr int ROW = NPROW * 16;               // uint2 {E, EB} entries per step: [pattern (SPLIT: low part, then high part)][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
+    static_assert(!GENERIC || (LDSBM && !SPLIT && NH % 4 == 0 && (!BMCHUNK || RC::CS == 4)), "generic kernels: whole patterns from the LDS ring");
+    // GENERIC: ring byte offset of the entry butterfly h of lane group q reads in layout step UP: [UP][q][h], filled below
+    __shared__ __attribute__((aligned(16))) u32 gen_tab[GENERIC ? PER * 4 * NH : 4];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
 
     // this kernel is VALU-issue bound; the chainback of the previous batch may be co-resident on a second stream: let
@@ -618,7 +638,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     // step `un` (un == U: step 0 of the NEXT block, whose chunks are already refilled).  Depends on symbols only, so it is
     // computed one step AHEAD, inside the basic block of the previous step's add-compare-select: its dependent chain
     // (perm -> sub -> neg -> max -> add -> sub) then overlaps ACS work instead of stalling the start of every step.
-    u32 E[2][BMCHUNK || SPLIT ? 1 : NP], EB[2][BMCHUNK || SPLIT ? 1 : NP];
+    u32 E[2][BMCHUNK || SPLIT ? 1 : NPF], EB[2][BMCHUNK || SPLIT ? 1 : NPF];
     // SPLIT, whole-step look-ahead (K = 7): the two parts as they come out of the ring -- {Elo, max_error - Elo} and Ehi
     u32 El[2][SPLIT && !BMCHUNK ? NPL : 1], EBl[2][SPLIT && !BMCHUNK ? NPL : 1], Eh[2][SPLIT && !BMCHUNK ? NPH : 1];
 #ifndef VIT_REG_CHUNK_AHEAD
@@ -731,11 +751,78 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         constexpr u32 tp = SP::bm_index(PHn, pv, off, nb);
         return (const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + base * 128 + (us % RING) * ROW * 8;
     };
+    // GENERIC: the offset table and the two rows in flight
+    u32 TG[2][!GENERIC ? 1 : BMCHUNK ? RC::CS : NH];
+    const u32 g8 = g * 8u;
+    const u32* gen_mine = gen_tab + q * NH;        // this lane group's rows
+    // BMCHUNK: the four offsets of sub-chunk s of block step un, into TG[s & 1] (sub-chunks are fetched in order, two rows in flight)
+    auto gen_chunk_row = [&](auto unc, auto sc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value, s = decltype(sc)::value, UPn = (un % U) % PER;
+        const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * s);
+        TG[s & 1][0] = v.x; TG[s & 1][1] = v.y; TG[s & 1][2] = v.z; TG[s & 1][3] = v.w;
+    };
+    auto gen_row = [&](auto unc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value, UPn = (un % U) % PER;
+        static_for<NH / 4>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * k);
+            TG[un & 1][4 * k] = v.x; TG[un & 1][4 * k + 1] = v.y; TG[un & 1][4 * k + 2] = v.z; TG[un & 1][4 * k + 3] = v.w;
+        });
+    };
+    if constexpr (GENERIC) {
+        // pat(v): bit i = parity((v << 1) & G[i])  (viterbi_branch_table.h:48-51), with the polynomials of the kernel arguments
+        auto pat_rt = [&](u32 v) __attribute__((always_inline)) -> u32 {
+            u32 p = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) p |= ((u32)__builtin_popcount((v << 1) & a.gen_G[i]) & 1u) << i;
+            return p;
+        };
+        for (u32 e = (u32)lane; e < (u32)(PER * 4 * NH); e += 64u) {
+            const u32 h = e % (u32)NH, qq = (e / (u32)NH) & 3u;
+            const int up = (int)(e / (u32)(4 * NH)), ph = up % SB;
+            // the register bit the butterflies of this step pair on (the step body's PB) and butterfly h's lower register
+            const bool lp = !X3 && SP::lane_phase(ph);
+            const int pb = (lp || (X3 && ph < SB - REG_BITS + 1)) ? T : SP::pbit(ph);
+            const u32 r0 = ((h >> pb) << (pb + 1)) | (h & ((1u << pb) - 1u));
+            // what the lane group contributes: RegSpec::pat_lane3 / pat_lane with the run-time pat
+            u32 x = 0;
+            if (X3) {
+                if (qq & 2u) x |= 1u << SP::lay(up, 0);
+                if (qq & 1u) x |= 1u << SP::lay(up, 1);
+            } else if (!lp) {
+                x = qq << REG_BITS;
+            } else {
+                const int lb = SP::pbit(ph) - REG_BITS;
+                if ((qq >> lb) & 1u) x |= 1u << T;
+                if ((qq >> (1 - lb)) & 1u) x |= 1u << (REG_BITS + (1 - lb));
+            }
+            gen_tab[e] = (pat_rt(SP::rotl(r0, ph)) ^ pat_rt(SP::rotl(x, ph))) << 7;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (BMCHUNK) {
+            gen_chunk_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            gen_chunk_row(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        } else {
+            gen_row(std::integral_constant<int, 0>{});
+            gen_row(std::integral_constant<int, 1>{});
+        }
+    }
     // LDSBM consumer: this lane's view of block step `un` (un == U: step 0 of the next block)
     auto bm_fetch = [&](auto unc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value;
         constexpr int us = un % U, buf = un & 1;
-        if constexpr (!SPLIT) {
+        if constexpr (GENERIC) {
+            // this step's row of the offset table was read two steps ago (TG[un & 1]); the row of step un + 2 takes its place
+            static_for<NH>([&](auto hc) __attribute__((always_inline)) {
+                constexpr int h = decltype(hc)::value;
+                const uint2 v = *(const uint2*)((const char*)bm_ring + (TG[buf][h] | g8) + (us % RING) * ROW * 8);
+                E[buf][h] = v.x;
+                EB[buf][h] = v.y;
+            });
+            gen_row(std::integral_constant<int, un + 2>{});
+        } else if constexpr (!SPLIT) {
             static_for<NP>([&](auto pc) __attribute__((always_inline)) {
                 constexpr int p = decltype(pc)::value;
                 const uint2 v = *(const uint2*)bm_entry(std::integral_constant<int, us>{}, std::integral_constant<u32, (u32)p>{}, std::integral_constant<int, 0>{});
@@ -759,6 +846,18 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     auto bm_fetch_chunk = [&](auto unc, auto sc) __attribute__((always_inline)) {
         constexpr int un = decltype(unc)::value, s = decltype(sc)::value;
         constexpr int us = un % U, PHn = us % PER, buf = s % NEB;
+        if constexpr (GENERIC) {
+            // the sub-chunk's row of the offset table was read two sub-chunks ago (TG[s & 1]); the row two sub-chunks on takes its place
+            static_assert(AHEAD == 1 && RC::NSUB % 2 == 0, "generic sub-chunk fetch: rows alternate between two buffers");
+            static_for<RC::CS>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const uint2 v = *(const uint2*)((const char*)bm_ring + (TG[s & 1][k] | g8) + (us % RING) * ROW * 8);
+                Ec[buf][k] = v.x;
+                EBc[buf][k] = v.y;
+            });
+            if constexpr (s + 2 < RC::NSUB) gen_chunk_row(unc, std::integral_constant<int, s + 2>{});
+            else gen_chunk_row(std::integral_constant<int, un + 1>{}, std::integral_constant<int, s + 2 - RC::NSUB>{});
+        } else
         static_for<RC::CS>([&](auto kc) __attribute__((always_inline)) {
             constexpr int h = s * RC::CS + decltype(kc)::value;
             if constexpr (!SPLIT) {
@@ -933,6 +1032,9 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         const u32 eh = Eh[cur][p >> RL];
                         e_p = pk_add(El[cur][p & (NPL - 1)], eh);
                         eb_p = pk_sub(EBl[cur][p & (NPL - 1)], eh);
+                    } else if constexpr (GENERIC) {
+                        e_p = E[cur][h];
+                        eb_p = EB[cur][h];
                     } else {
                         e_p = E[cur][p];
                         eb_p = EB[cur][p];
@@ -1129,11 +1231,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
 #ifndef VIT_REG_FOLD
 #define VIT_REG_FOLD 1
 #endif
-                        constexpr bool FOLD = VIT_REG_FOLD && SP::LANE_BITS != 0 && !BMCHUNK && !SPLIT && 2 * NP < NREG;
+                        constexpr bool FOLD = VIT_REG_FOLD && SP::LANE_BITS != 0 && !BMCHUNK && !SPLIT && 2 * NPF < NREG;
                         bool folded = false;
                         if constexpr (FOLD) {
                             if ((!GUARDED && u + 1 < U) || t0 + (u32)u + 1u < a.t_end) {
-                                static_for<NP>([&](auto pc) __attribute__((always_inline)) {
+                                static_for<NPF>([&](auto pc) __attribute__((always_inline)) {
                                     constexpr int pp = decltype(pc)::value;
                                     E[(u + 1) & 1][pp] = pk_sub(E[(u + 1) & 1][pp], sub);
                                     EB[(u + 1) & 1][pp] = pk_sub(EB[(u + 1) & 1][pp], sub);
@@ -1159,6 +1261,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                         constexpr int sl = (Jb + 1) % NG;
                         bm_produce(std::integral_constant<int, GROUP * (Jb + 1)>{}, std::integral_constant<int, sl>{});
                         load_group(t0 + (u32)(GROUP * (Jb + 1 + NG)), std::integral_constant<int, sl>{});
+                    }
+                    if constexpr (GENERIC) {
+                        // the skipped butterflies' fetches would have moved the offset rows on: put the next step's first two in place
+                        gen_chunk_row(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 0>{});
+                        gen_chunk_row(std::integral_constant<int, u + 1>{}, std::integral_constant<int, 1>{});
                     }
                     static_for<AHEAD>([&](auto ac) __attribute__((always_inline)) { bm_fetch_chunk(std::integral_constant<int, u + 1>{}, ac); });
                 }
@@ -1909,7 +2016,11 @@ struct RegCode {
     int tile = 32; // frames per wavefront
     uint32_t G[6] = {0, 0, 0, 0, 0, 0};
     const RegJitModule* jit = nullptr;
+    bool generic = false;   // jit is the GENERIC code object of (K, R): the kernels read G from their arguments (RegSpec::GENERIC)
 };
+
+// (K, R) with a generic register-plan kernel: the LDS-ring geometries (K = 7: whole-step fetch, K = 8, 9: per sub-chunk) at whole patterns
+inline bool reg_generic_supported(int K, int R) { return K >= 7 && K <= 9 && R >= 2 && R <= 4; }
 
 inline bool reg_code_supported(int K, int R) {
     return (K == 7 && R >= 2 && R <= 4) || (K == 9 && (R == 2 || R == 4)) || ((K == 3 || K == 5) && R == 2);
@@ -2094,6 +2205,7 @@ inline int reg_update(const RegCode& rc, const DevConfig& cfg, int shift, const 
     a.t_begin = (u32)first_step;
     a.t_end = (u32)(first_step + n_steps);
     a.cfg = cfg;
+    for (int i = 0; i < 6; ++i) a.gen_G[i] = rc.G[i];
 #ifdef VIT_HIP_CLOCK_STAMPS
     a.stamps = g_clock_stamps;
 #endif

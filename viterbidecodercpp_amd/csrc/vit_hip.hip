@@ -180,11 +180,22 @@ int lds_chainback(vit_hip_handle h, const uint64_t* d_decisions, size_t frames, 
 // run-time compiled PLAN_REG for polynomials outside the ahead-of-time table (reg_jit.hpp)
 // package_only: load an install-time precompiled code object if the package cache holds one; compile nothing
 bool try_reg_jit(vit_hip_handle h, bool package_only) {
-    if (h->reg_ok) return true;
+    // (a handle on the GENERIC kernels asks again when the caller allows compiling: kernels specialised for its polynomials are faster)
+    if (h->reg_ok && !(h->reg_code.generic && !package_only)) return true;
     if (!h->linear || !vit::reg_jit_supported(h->K, h->R)) return false;
     std::string err;
     const vit::RegJitModule* m = vit::reg_jit_get(h->K, h->R, h->G, h->shift, h->device, package_only, err, &h->reg_origin);
+    bool generic = false;
+    if (!m && vit::reg_generic_supported(h->K, h->R)) {
+        // no kernels specialised for these polynomials (and, unless package_only, no compiler to make them): the GENERIC code object
+        // of this (K, R) -- polynomials read from the kernel arguments (RegSpec::GENERIC) -- if the package cache holds it
+        const uint32_t zero[6] = {0, 0, 0, 0, 0, 0};
+        std::string err2;
+        m = vit::reg_jit_get(h->K, h->R, zero, h->shift, h->device, true, err2, &h->reg_origin);
+        generic = m != nullptr;
+    }
     if (!m) {
+        if (h->reg_ok) return true;             // the upgrade failed: the generic kernels stay
         if (!package_only) g_last_error = err;
         return false;
     }
@@ -193,6 +204,8 @@ bool try_reg_jit(vit_hip_handle h, bool package_only) {
     h->reg_code.R = h->R;
     h->reg_code.tile = h->K < 7 ? 128 : 32;
     h->reg_code.jit = m;
+    h->reg_code.generic = generic;
+    for (int i = 0; i < 6; ++i) h->reg_code.G[i] = i < h->R ? h->G[i] : 0u;
     h->reg_ok = true;
     return true;
 }
@@ -408,7 +421,9 @@ static int vit_hip_create_impl(int K, int R, int soft_bytes, int error_bytes, co
     if (!h->reg_ok && h->linear && vit::reg_jit_supported(K, R)) {
         // a code object precompiled at install time (package cache, reg_jit.hpp) is as good as a built-in one: no compiler runs
         const char* e = getenv("VIT_HIP_JIT");
-        if (!try_reg_jit(h, true) && e && *e == '1') (void)try_reg_jit(h, false);   // compiling: opt-in at create time; vit_hip_set_plan(PLAN_REG) always tries
+        // compiling: opt-in at create time (vit_hip_set_plan(PLAN_REG) always tries); either way the search ends at the package's GENERIC kernels
+        if (e && *e == '1') (void)try_reg_jit(h, false);
+        else (void)try_reg_jit(h, true);
     }
     h->lds2_ok = h->linear && vit::lds2_supported(K, R);   // the group-B tables rely on the code being linear
     h->plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
@@ -441,6 +456,9 @@ const char* vit_hip_plan_note(vit_hip_handle h) {
     if (h->plan == VIT_HIP_PLAN_REG && h->reg_code.jit) {
         const bool pkg = h->reg_origin.compare(0, vit::package_cache_dir().size(), vit::package_cache_dir()) == 0;
         note += std::string(pkg ? "; kernels precompiled at install time, loaded from the package cache " : "; kernels compiled at run time, loaded from the user cache ") + h->reg_origin;
+        if (h->reg_code.generic)
+            note += "; these are the GENERIC kernels of this (K, R) -- polynomials read at run time, about 5 % behind kernels specialised for them: "
+                    "python -m viterbidecodercpp_amd.tools.precompile K R G... at install time, or VIT_HIP_JIT=1 before vit_hip_create (hipcc), gets those";
     }
     if (h->plan == VIT_HIP_PLAN_LDS) {
         if (h->reg_ok || (h->linear && vit::reg_jit_supported(h->K, h->R)))
@@ -473,7 +491,9 @@ int vit_hip_get_info(vit_hip_handle h, vit_hip_info* info) {
 static int vit_hip_set_plan_impl(vit_hip_handle h, int plan) {
     if (!h) return fail(VIT_HIP_ERR_INVALID_ARG, "NULL handle");
     if (plan == VIT_HIP_PLAN_AUTO) plan = h->reg_ok ? VIT_HIP_PLAN_REG : h->lds2_ok ? VIT_HIP_PLAN_LDS2 : VIT_HIP_PLAN_LDS;
-    if (plan == VIT_HIP_PLAN_REG && !h->reg_ok) {
+    // (a handle on the package's GENERIC kernels: asking for the register plan by name looks for kernels specialised for its polynomials --
+    // package cache, user cache, compiler -- and keeps the generic ones when there are none)
+    if (plan == VIT_HIP_PLAN_REG && (!h->reg_ok || (h->reg_code.jit && h->reg_code.generic))) {
         DeviceGuard guard(h->device);
         g_last_error.clear();
         if (!guard.ok || !try_reg_jit(h, false))
@@ -1603,6 +1623,13 @@ static int vit_hip_precompile_impl(int K, int R, const uint32_t* polynomials, in
     // the same normal form vit_hip_create recovers from a branch table: bit 0 and bit K-1 of every polynomial set
     uint32_t G[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < R; ++i) G[i] = (polynomials[i] & ((1u << K) - 1u)) | 1u | (1u << (K - 1));
+    // all polynomials zero: the GENERIC kernels of (K, R), which read the polynomials from their arguments (RegSpec::GENERIC)
+    bool generic = true;
+    for (int i = 0; i < R; ++i) generic = generic && polynomials[i] == 0;
+    if (generic) {
+        if (!vit::reg_generic_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "generic register-plan kernels exist for K = 7..9 with R = 2..4");
+        for (int i = 0; i < R; ++i) G[i] = 0;
+    }
     std::string err;
     const int shift = soft_bytes == 1 ? 8 : 0;
     const std::string name = vit::reg_jit_object_name(K, R, G, shift, err);

@@ -29,7 +29,10 @@ COMMON_SETS = [
     ("GSM K=5 R=1/2", 5, 2, (0o23, 0o33)),
     ("UMTS / LTE-CC K=9 R=1/2", 9, 2, (0o561, 0o753)),
     ("UMTS K=9 R=1/3", 9, 3, (0o557, 0o663, 0o711)),
+    # all polynomials zero: the GENERIC kernels of (K, R) -- polynomials read at run time, one code object for every set (what
+    # vit_hip_create falls back to when neither the library nor this cache holds kernels specialised for a set)
 ]
+COMMON_SETS += [(f"GENERIC K={K} R=1/{R} (any polynomials)", K, R, (0,) * R) for K in (7, 8, 9) for R in (2, 3, 4)]
 
 
 def parse_list(path):
