@@ -28,13 +28,19 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None, chainback_ke
              (COMMON_CODES[1], _lib.PLAN_REG), (Code("K11", 11, 2, (0o3345, 0o3613)), _lib.PLAN_LDS2),
              (Code("K10", 10, 3, (0o1117, 0o1365, 0o1633)), _lib.PLAN_LDS2),
              (Code("K12", 12, 3, (0o4335, 0o5723, 0o7221)), _lib.PLAN_LDS2), (COMMON_CODES[7], _lib.PLAN_LDS2),
-             (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS), (Code("K16", 16, 2, (46749, 58851)), _lib.PLAN_LDS2)]
+             (Code("K6", 6, 2, (0o65, 0o57)), _lib.PLAN_LDS), (Code("K16", 16, 2, (46749, 58851)), _lib.PLAN_LDS2),
+             # polynomials drawn per seed, PLAN_AUTO: the GENERIC register-plan kernels (K = 7, 8, 9; R = 2, 3, 4), which read them at run time
+             (7, _lib.PLAN_AUTO), (8, _lib.PLAN_AUTO), (9, _lib.PLAN_AUTO)]
     t_end = time.time() + budget_seconds
     seed, n = first_seed, 0
     while time.time() < t_end:
-        for ci, (code, plan) in enumerate(cases):
+        for ci, (code0, plan) in enumerate(cases):
             for width in (2, 1):
                 rng = np.random.default_rng(100000 * seed + 10 * ci + width)
+                code = code0
+                if isinstance(code0, int):
+                    K, R = code0, int(rng.integers(2, 5))
+                    code = Code(f"K{K} generic", K, R, tuple(int(x) | 1 | (1 << (K - 1)) for x in rng.integers(0, 1 << K, R)))
                 trial = int(rng.integers(0, 4))
                 cfg = random_config(rng, width, trial)
                 sdt = np.int16 if width == 2 else np.int8
@@ -56,6 +62,8 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None, chainback_ke
                         for f in range(F)]
                 d_sym = torch.from_numpy(sym).cuda()
                 dec = BatchDecoder(table, config, plan=plan)
+                if plan == _lib.PLAN_AUTO:
+                    assert dec.plan == _lib.PLAN_REG, dec.plan_note
                 if n % 3 == 2:          # streamed: two chunks through the resumed update
                     cut = int(rng.integers(1, S)) if S > 1 else 1
                     met = dec.reset_batch(F, start_state=ss)
@@ -70,7 +78,7 @@ def soak(budget_seconds: float, first_seed: int = 1, progress=None, chainback_ke
                 met = met.cpu().numpy()
                 met = met.view(np.uint16) if width == 2 else met
                 for f in range(F):
-                    tag = (seed, code.name, plan, width, f, L, cfg)
+                    tag = (seed, code.name, code.G, plan, width, f, L, cfg)
                     assert np.array_equal(got_dec[f], want[f]["decisions"]), ("decisions", tag)
                     assert np.array_equal(met[f].astype(np.uint32), want[f]["metrics"]), ("metrics", tag)
                     assert int(rs[f].item()) == want[f]["renorm_sum"], ("renorm", tag)

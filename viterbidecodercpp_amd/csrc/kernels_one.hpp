@@ -158,7 +158,7 @@ __device__ __forceinline__ void one_update_body(const OneUpdateArgs& a) {
             const bool d = m0 > m1;                                            // strict: tie -> 0        :123-124
             m = m0 < m1 ? m0 : m1;                                             // d ? m1 : m0             :127-128
             const uint64_t word = __ballot(d) & live;                          // :131-134
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(w_lo) : "s"((uint32_t)word), "n"(k));
+            asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(w_lo) : "s"((uint32_t)word), "n"(k));   // (s_nop: see one_update7_body)
             asm("v_writelane_b32 %0, %1, %2" : "+v"(w_hi) : "s"((uint32_t)(word >> 32)), "n"(k));
             m_state0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);      // tested behind the NEXT step's fetches (or after the last step)
             }
@@ -178,8 +178,327 @@ __device__ __forceinline__ void one_update_body(const OneUpdateArgs& a) {
     if (lane == 0) a.renorm_sum[0] = acc;
 }
 
+// ---- K = 7 (64 states: a full wavefront), R <= 4: the IN-PLACE trellis with two helper wavefronts (round 6, second session) ----
+// The body above pays two LDS round trips and ~22 instructions per step (70 ns).  What a step of a lone wavefront costs is the length
+// of its DEPENDENT chain and the instructions on it; everything that is not the add-compare-select itself moves to other wavefronts of
+// the workgroup, which has three:
+//   * wave 0 walks the trellis with the index rotation of the batch kernels (kernels_reg.hpp): at step t (phase ph = t mod 6) lane l
+//     holds state rotl^ph(l), the butterfly {(0|X),(1|X)} -> {(X|0),(X|1)} reads and writes the two lanes that differ in lane bit
+//     p = 5 - ph, and the lane whose bit p is b makes state (X|b).  Both members' metrics reach both lanes with one swap
+//     (v_permlane32_swap / v_permlane16_swap of the register with its copy: every lane then holds (lo member, hi member)) or two
+//     bank-masked DPP moves (row_shr / row_shl by 8 or 4, quad_perm for the two low bits) -- no LDS crossbar on the chain;
+//     u = lo + eu, v = hi + ev, new = min(u, v) (written twice: the next exchange consumes two copies), decision = u > v (strict,
+//     scalar.h:123-124) pushed into a per-lane history word by ONE v_addc (carry-in = the compare's VCC).  The lane's
+//     (eu, ev) = (b ? max_error - e : e, b ? e : max_error - e) of its butterfly's branch pattern is ONE ds_read_b64, four steps
+//     ahead, out of a table wave 1 has made.  Chain: exchange -> add -> min; 10 instructions per step.
+//     The threshold test (scalar.h:48-50) would add a v_cmp and a scalar branch that waits for it: 9 of 36 ns.  A whole block of 32
+//     steps CANNOT renormalise when state 0's metric plus 32 times the block's largest branch metric stays below the threshold
+//     (new[0] <= old[0] + e, :113,:127; wave 1 publishes the maximum with the table): such blocks run a copy of the loop without the
+//     test, the others test every step -- one step LATE, behind the next step's exchange and adds, on which the subtraction of the
+//     minimum is made up (it commutes with both; the decisions of the step that tripped are final).
+//   * wave 1, lane == step: per block of 32 steps it forms {e, max_error - e} of all 2^R patterns for both b (scalar.h:66-73,:107)
+//     from symbols it fetched a whole period of six blocks earlier (host-mapped memory on the frame route: the PCIe round trip must
+//     not become the step time -- and it did, twice: behind __syncthreads(), whose fence drains vmcnt, and behind the single
+//     vmcnt(0) hipcc puts at the top of a loop that joins paths with different loads in flight: the six loads of the NEXT period
+//     are issued right behind that wait, so that everything it waits for is a period old).  Loads only in this wavefront: with the
+//     row stores beside them every use of a symbol waited for vmcnt(0) (loads and stores retire out of order against each other).
+//   * wave 2, lane == next-state: it turns the block of history words wave 0 parked in LDS into the reference's decision rows: lane
+//     s' reads the history word of the lane that held s' (a rotation of its own index by the row's phase), one bit per row -> v_cmp ->
+//     the 64-bit row, parked with v_writelane and stored coalesced, 256 bytes per block.  Rows in HBM are the reference's (chainback,
+//     export and the host's m_decisions never see the rotation).
+// One hardware barrier per block of 32 steps hands the table and the history over (LDS only: s_waitcnt lgkmcnt(0) + s_barrier).
+// Results are bit for bit the body's above; 30 ns per step (scripts/host_route_latency.py; profiles/r6_frame_route.txt).
+template <int R, int SHIFT>
+__device__ __forceinline__ void one_update7_body(const OneUpdateArgs& a) {
+    static_assert(R >= 1 && R <= 4, "the per-step table holds 2^(R+1) entries");
+    constexpr int NPAT = 1 << R;
+    constexpr int ROWB = NPAT * 16;            // bytes per step: [pattern]{b = 0: (e, M - e), b = 1: (M - e, e)} as four dwords
+    constexpr int BLK = 32, SUP = 96;          // steps per block / per unrolled super-block (whole phases: 96 = 16 x 6)
+    __shared__ __attribute__((aligned(16))) uint32_t one_bm[SUP * NPAT * 4];
+    __shared__ uint32_t one_hist[2][64];
+    __shared__ uint32_t one_emax[3];           // per ring third: the largest branch metric of the block (what a step can add to a path at most)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_steps = a.n_steps;
+    const int nblocks = (n_steps + BLK - 1) / BLK;
+    // every wavefront meets at the barrier nbar times inside its loop: the blocks, rounded up to the producer's unrolled period -- its
+    // loop then has no conditional in it, and hipcc can count its loads (a join of paths with different numbers of loads in flight
+    // makes it wait for vmcnt(0), i.e. for the PCIe round trip of the newest)
+    constexpr int NS = 6;                              // blocks between the fetch of a step's symbols and their use
+    const int nbar = (nblocks + NS - 1) / NS * NS;
+    const uint32_t max_error = a.cfg.max_error, threshold = a.cfg.threshold;
+    // The per-block hand-over concerns LDS only (table rows one way, history words the other): wait for this wave's LDS operations and
+    // meet at the hardware barrier.  NOT __syncthreads(): its workgroup-scope fence also drains vmcnt, i.e. the helper would sit out
+    // the PCIe round trip of the symbols it has just asked for at EVERY block (first build: 1.65 us per block whatever wave 0 did)
+    // (sched_barrier: hipcc otherwise hoists the arithmetic on every symbol slot to the top of the producer's unrolled loop, and with it
+    // one wait for ALL the loads in flight)
+    auto lds_barrier = []() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto rotl6 = [](uint32_t x, int n) __attribute__((always_inline)) -> uint32_t { return n == 0 ? x : (((x << n) | (x >> (6 - n))) & 63u); };
+    auto rotr6 = [&](uint32_t x, int n) __attribute__((always_inline)) -> uint32_t { return rotl6(x, (6 - n) % 6); };
+
+    if (wave == 0) {
+        // ---------------- the trellis ----------------
+        uint32_t m = a.metrics_in_args ? (uint32_t)a.metrics_in[lane]
+                   : SHIFT ? (uint32_t)(((const uint8_t*)a.metrics_io)[lane]) << 8 : (uint32_t)((const uint16_t*)a.metrics_io)[lane];
+        // where this lane's (eu, ev) sits inside a step's table row, per phase: pattern of butterfly X = rotl^ph(lane without bit p)
+        uint32_t tab[6];
+#pragma unroll
+        for (int ph = 0; ph < 6; ++ph) {
+            const int pbit = 5 - ph;
+            const uint32_t b = ((uint32_t)lane >> pbit) & 1u;
+            const uint32_t X = rotl6((uint32_t)lane & ~(1u << pbit), ph);          // (0|X): below 32
+            tab[ph] = ((uint32_t)(a.pattern[X] & (NPAT - 1)) * 2u + b) * 8u;
+        }
+        uint64_t acc = 0;
+        uint32_t hist = 0;
+        auto renormalise = [&]() __attribute__((always_inline)) {
+            uint32_t mn = m;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)mn, off);
+                mn = o < mn ? o : mn;
+            }
+            m = (m - mn) & 0xFFFFu;
+            acc += (uint64_t)(mn >> SHIFT);
+        };
+        const uint32_t thr_lane = lane == 0 ? threshold : 0xFFFFFFFFu;
+        lds_barrier();                                 // the helper's table of block 0
+        // the lane's (eu, ev) of super-block step ts: fetched several steps ahead of its use (an LDS round trip is longer than a step)
+        auto fetch = [&](auto tc) __attribute__((always_inline)) -> uint2 {
+            constexpr int ts = decltype(tc)::value;
+            return *(const uint2*)((const char*)one_bm + tab[ts % 6] + ts * ROWB);
+        };
+        // The dependent chain of a step is exchange -> add -> min; everything else hangs off its side.  Two things keep it that short:
+        // the minimum is written TWICE (m and m2), so that the exchange -- which consumes two copies of the register -- needs no move
+        // in front of it; and the threshold test of step t (a v_cmp into a scalar pair) is only BRANCHED on behind the issue of step
+        // t + 1's exchange, which ran on the untested metrics: the rare branch renormalises and exchanges again (the decisions of the
+        // step that tripped are final, and the exchange is the only reader of the metrics in front of the test) -- on the exchanged pair.
+        uint32_t m2 = m;
+        uint64_t pend = 0;                             // lanes whose new metric reached the threshold in the previous step (lane 0 or none)
+        auto exchange = [&](auto phc, uint32_t& lo, uint32_t& hi) __attribute__((always_inline)) {
+            constexpr int PH = decltype(phc)::value;
+            if constexpr (PH == 0) {
+                auto r2 = __builtin_amdgcn_permlane32_swap(m, m2, false, false);
+                lo = r2[0]; hi = r2[1];
+            } else if constexpr (PH == 1) {
+                auto r2 = __builtin_amdgcn_permlane16_swap(m, m2, false, false);
+                lo = r2[0]; hi = r2[1];
+            } else if constexpr (PH == 2) {        // lane bit 3: row_shr:8 into banks 2, 3; row_shl:8 into banks 0, 1
+                lo = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m2, 0x118, 0xF, 0xC, false);
+                hi = (uint32_t)__builtin_amdgcn_update_dpp((int)m2, (int)m2, 0x108, 0xF, 0x3, false);
+            } else if constexpr (PH == 3) {        // lane bit 2: row_shr:4 into banks 1, 3; row_shl:4 into banks 0, 2
+                lo = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m2, 0x114, 0xF, 0xA, false);
+                hi = (uint32_t)__builtin_amdgcn_update_dpp((int)m2, (int)m2, 0x104, 0xF, 0x5, false);
+            } else if constexpr (PH == 4) {        // lane bit 1: quad_perm [0,1,0,1] / [2,3,2,3]
+                lo = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m2, 0x44, 0xF, 0xF, false);
+                hi = (uint32_t)__builtin_amdgcn_update_dpp((int)m2, (int)m2, 0xEE, 0xF, 0xF, false);
+            } else {                               // lane bit 0: quad_perm [0,0,2,2] / [1,1,3,3]
+                lo = (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m2, 0xA0, 0xF, 0xF, false);
+                hi = (uint32_t)__builtin_amdgcn_update_dpp((int)m2, (int)m2, 0xF5, 0xF, 0xF, false);
+            }
+        };
+        // TEST = false: a block that CANNOT renormalise (state 0's metric plus 32 times the block's largest branch metric stays below
+        // the threshold: new[0] <= old[0] + e, scalar.h:113,:127) runs without the per-step test -- a v_cmp whose result a scalar branch
+        // waits for costs a lone wavefront 9 of a step's 36 ns
+        auto step = [&](auto tc, auto testc, const uint2 bm) __attribute__((always_inline)) {
+            constexpr int ts = decltype(tc)::value;        // step inside the super-block: phase and table slot are compile time
+            constexpr int PH = ts % 6;
+            constexpr bool TEST = decltype(testc)::value;
+            uint32_t lo, hi;
+            exchange(std::integral_constant<int, PH>{}, lo, hi);
+            // candidates in the low 16 bits (whatever the adds carry above them is ignored by the 16-bit compare and minimum, and the
+            // minimum writes zeros there)
+            uint32_t u = lo + bm.x, v = hi + bm.y;
+            if constexpr (TEST) asm volatile("" : "+v"(u), "+v"(v), "+v"(lo), "+v"(hi));        // issued in front of the branch, not sunk behind it
+            // renormalise when new_metric[0] >= threshold (:48-50), the PREVIOUS step's: state 0 is lane 0 in every phase.  On the
+            // exchanged pair (every state's metric is some lane's lo or hi), and behind the adds: subtracting the minimum commutes with
+            // both, and the scalar branch has the exchange AND the adds between it and the v_cmp it waits for
+            if (TEST && __builtin_expect(pend != 0, 0)) {
+                uint32_t mn = (lo & 0xFFFFu) < (hi & 0xFFFFu) ? lo : hi;
+                mn &= 0xFFFFu;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)mn, off);
+                    mn = o < mn ? o : mn;
+                }
+                u -= mn; v -= mn;                      // (mod 2^16: only the low halves are read from here on)
+                acc += (uint64_t)(mn >> SHIFT);
+            }
+            // decision = u > v (tie -> 0, :123-124) straight into the history word (hist = 2 hist + carry), new metric = the smaller (:127-128)
+            uint32_t &hs = hist, &mm = m, &mm2 = m2;
+            asm volatile("v_cmp_gt_u16 vcc, %3, %4\n\tv_min_u16 %1, %3, %4\n\tv_min_u16 %2, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                         : "+v"(hs), "=&v"(mm), "=&v"(mm2) : "v"(u), "v"(v) : "vcc");
+            // the other lanes compare against a value no metric reaches: one v_cmp into a scalar pair, branched on one step later
+            if constexpr (TEST) pend = __builtin_amdgcn_ballot_w64(m >= thr_lane);
+        };
+        for (int b0 = 0; b0 < nblocks; b0 += 3) {
+            one_static_for<3>([&](auto bbc) __attribute__((always_inline)) {
+                constexpr int bb = decltype(bbc)::value;
+                if (b0 + bb < nblocks) {
+                    const int nb = n_steps - (b0 + bb) * BLK < BLK ? n_steps - (b0 + bb) * BLK : BLK;
+                    constexpr int QD = 4;                        // table rows in flight (2, 4, 8: the same step time)
+                    uint2 q[QD];
+                    one_static_for<QD>([&](auto dc) __attribute__((always_inline)) { q[decltype(dc)::value] = fetch(std::integral_constant<int, bb * BLK + decltype(dc)::value>{}); });
+                    // can state 0 reach the threshold inside this block?  (whole blocks only; a threshold of 0 -- "always" -- never passes)
+                    bool safe = false;
+                    if (nb == BLK) {
+                        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+                        const uint32_t em = (uint32_t)__builtin_amdgcn_readfirstlane((int)one_emax[bb]);
+                        safe = m0 + (uint32_t)BLK * em < threshold;
+                    }
+                    auto one = [&](auto kc, auto testc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        const uint2 bm = q[k % QD];
+                        if constexpr (k + QD < BLK) q[k % QD] = fetch(std::integral_constant<int, bb * BLK + k + QD>{});   // (rows of THIS block only: the next one's appear behind the barrier)
+                        step(std::integral_constant<int, bb * BLK + k>{}, testc, bm);
+                    };
+                    if (safe) {
+                        one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { one(kc, std::false_type{}); });
+                    } else {
+                        if (nb == BLK) {
+                            one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { one(kc, std::true_type{}); });
+                        } else {
+                            one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { if (decltype(kc)::value < nb) one(kc, std::true_type{}); });
+                            hist <<= (BLK - nb);           // the block's first step at bit 31
+                        }
+                        // the block's last test is settled here (every block starts with nothing pending)
+                        if (pend != 0) { renormalise(); m2 = m; pend = 0; }
+                    }
+                    one_hist[(b0 + bb) & 1][lane] = hist;
+                    lds_barrier();
+                }
+            });
+        }
+        for (int b = nblocks; b < nbar; ++b) lds_barrier();
+        __syncthreads();                               // (the helper's last conversion)
+        const uint32_t st = rotl6((uint32_t)lane, n_steps % 6);     // the state this lane holds after the last step
+        if (SHIFT) ((uint8_t*)a.metrics_io)[st] = (uint8_t)(m >> 8);
+        else ((uint16_t*)a.metrics_io)[st] = (uint16_t)m;
+        if (lane == 0) a.renorm_sum[0] = acc;
+    } else if (wave == 1) {
+        // ---------------- helper 1: branch-metric tables ahead of the trellis ----------------
+        // (loads only: with the row stores in the same wavefront hipcc must wait for vmcnt(0) in front of every use of a symbol --
+        // loads and stores retire out of order against each other -- i.e. for the PCIe round trip of the loads it has JUST issued)
+        const int16_t* sym16 = (const int16_t*)a.symbols;
+        const int8_t* sym8 = (const int8_t*)a.symbols;
+        // symbols of the lane's step of blocks x (mod NS): fetched NS blocks ahead of their use -- on the frame route they come from
+        // host memory, and the round trip over PCIe (several microseconds) must not become the step time.  Unconditional loads (steps
+        // beyond the call's last repeat it: their table rows are never read)
+        int32_t ys[NS][R], yn[NS][R];                  // the set in use (blocks 6j + 1 .. 6j + 6) and the set in flight (the next six)
+        auto load_syms = [&](int x, int32_t (&dst)[R]) __attribute__((always_inline)) {
+            int t = x * BLK + (lane & (BLK - 1));
+            t = t < n_steps ? t : n_steps - 1;
+#pragma unroll
+            for (int i = 0; i < R; ++i) dst[i] = SHIFT ? (int32_t)sym8[(size_t)t * R + i] : (int32_t)sym16[(size_t)t * R + i];   // (8-bit: shifted in produce)
+        };
+        // the table rows of block x (slot = step mod 96; the two halves of the wavefront write the same rows)
+        auto produce = [&](auto bbc, const int32_t (&yy)[R]) __attribute__((always_inline)) {
+            constexpr int bb = decltype(bbc)::value % 3;   // x mod 3: ring third
+            uint32_t a0[R], a1[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int32_t y = SHIFT ? (int32_t)(int16_t)(uint16_t)((uint32_t)yy[i] << 8) : yy[i];      // the device's 16-bit domain
+                a0[i] = abs_soft(a.cfg.low, y); a1[i] = abs_soft(a.cfg.high, y);
+            }
+            uint4* row = (uint4*)((char*)one_bm + (bb * BLK + (lane & (BLK - 1))) * ROWB);
+            uint32_t emax = 0;
+#pragma unroll
+            for (int p = 0; p < NPAT; ++p) {
+                uint32_t e = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) e += ((p >> i) & 1) ? a1[i] : a0[i];
+                e &= 0xFFFFu;
+                const uint32_t eb = (max_error - e) & 0xFFFFu;
+                row[p] = make_uint4(e, eb, eb, e);
+                emax = e > emax ? e : emax;
+                emax = eb > emax ? eb : emax;
+            }
+            // the block's largest (the two halves of the wavefront hold the same 32 steps)
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)emax, off);
+                emax = o > emax ? o : emax;
+            }
+            if (lane == 0) one_emax[bb] = emax;
+        };
+        static_assert(NS % 3 == 0, "the unrolled period names the ring thirds");
+        // hipcc joins the paths into the loop with ONE wait for everything in flight at its top: so everything in flight there is a
+        // whole period (six blocks, ~5 us) old -- the six loads of the NEXT period are issued right behind that wait
+        {
+            int32_t y0[R];
+            load_syms(0, y0);
+            one_static_for<NS>([&](auto sc) __attribute__((always_inline)) { load_syms(1 + decltype(sc)::value, yn[decltype(sc)::value]); });
+            produce(std::integral_constant<int, 0>{}, y0);
+        }
+        lds_barrier();                                 // table of block 0 in place
+        for (int b0 = 0; b0 < nbar; b0 += NS) {
+            one_static_for<NS>([&](auto sc) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) ys[decltype(sc)::value][i] = yn[decltype(sc)::value][i];
+            });
+            one_static_for<NS>([&](auto sc) __attribute__((always_inline)) { load_syms(b0 + NS + 1 + decltype(sc)::value, yn[decltype(sc)::value]); });
+            one_static_for<NS>([&](auto bbc) __attribute__((always_inline)) {
+                constexpr int bb = decltype(bbc)::value;
+                produce(std::integral_constant<int, (bb + 1) % NS>{}, ys[bb]);    // block b0 + bb + 1 (beyond the last: rows nobody reads)
+                lds_barrier();
+            });
+        }
+        __syncthreads();
+    } else {
+        // ---------------- helper 2: the reference's decision rows behind the trellis ----------------
+        // history words of block xb (one_hist[xb & 1]) -> the reference's rows of its nb steps
+        uint32_t src[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) src[c] = rotr6((uint32_t)lane, c);         // the lane that held next-state `lane` in a row of phase c
+        uint32_t w_lo = 0, w_hi = 0;                   // the rows this lane parks: row `lane` of the block being converted
+        auto convert = [&](int xb, auto bbc) __attribute__((always_inline)) {
+            constexpr int bb = decltype(bbc)::value;   // xb mod 3
+            const int nb = n_steps - xb * BLK < BLK ? n_steps - xb * BLK : BLK;
+            uint32_t h[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) h[c] = one_hist[xb & 1][src[c]];
+            one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int c = (bb * BLK + k + 1) % 6;           // row t = 32 xb + k holds the states AFTER step t
+                const uint64_t word = __ballot((h[c] >> (31 - k)) & 1u);
+                uint32_t &wl = w_lo, &wh = w_hi;           // (named here: an asm operand alone does not make the lambda capture them)
+                // s_nop: the row comes straight out of a v_cmp (often into VCC), and a v_writelane that reads a scalar register the
+                // instruction in front of it has written gets the OLD value -- hipcc cannot see into the asm to pad it (first build:
+                // the low word of every row whose compare had nothing between it and the v_writelane was stale)
+                asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(wl) : "s"((uint32_t)word), "n"(k));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(wh) : "s"((uint32_t)(word >> 32)), "n"(k));
+            });
+            if (lane < nb) a.decisions[(size_t)xb * BLK + (size_t)lane] = ((uint64_t)w_hi << 32) | w_lo;
+        };
+        lds_barrier();
+        for (int b0 = 0; b0 < nblocks; b0 += 3) {
+            one_static_for<3>([&](auto bbc) __attribute__((always_inline)) {
+                constexpr int bb = decltype(bbc)::value;
+                const int b = b0 + bb;
+                if (b < nblocks) {
+                    if (b > 0) convert(b - 1, std::integral_constant<int, (bb + 2) % 3>{});
+                    lds_barrier();
+                }
+            });
+        }
+        for (int b = nblocks; b < nbar; ++b) lds_barrier();
+        if (nblocks > 0) {
+            const int xb = nblocks - 1;
+            if (xb % 3 == 0) convert(xb, std::integral_constant<int, 0>{});
+            else if (xb % 3 == 1) convert(xb, std::integral_constant<int, 1>{});
+            else convert(xb, std::integral_constant<int, 2>{});
+        }
+        __syncthreads();
+    }
+}
+inline bool one_update7_supported(int K, int R) { return K == 7 && R >= 1 && R <= 4; }
+
 template <int R, int SHIFT>
 __global__ void __launch_bounds__(64) one_update_kernel(OneUpdateArgs a) { one_update_body<R, SHIFT>(a); }
+template <int R, int SHIFT>
+__global__ void __launch_bounds__(192) one_update7_kernel(OneUpdateArgs a) { one_update7_body<R, SHIFT>(a); }
 
 struct OneChainbackArgs {
     const uint64_t* decisions;   // [L + K-1] words
@@ -305,11 +624,35 @@ __global__ void __launch_bounds__(64) one_frame_kernel(OneFrameArgs a) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.done, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before this
 }
 
+template <int R, int SHIFT>
+__global__ void __launch_bounds__(192) one_frame7_kernel(OneFrameArgs a) {
+    extern __shared__ uint64_t one_rows_smem[];
+    one_update7_body<R, SHIFT>(a.u);
+    if (threadIdx.x >= 64) return;                          // the helper wavefronts are done (a wave that has ended leaves the barriers below)
+    if (a.do_chainback) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the helper's row stores: complete (its last barrier is behind them) and visible
+        __syncthreads();
+        one_chainback_body(a.c, one_rows_smem);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.done, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr size_t one_chainback_lds_bytes() { return ((size_t)ONE_CB_CHUNK + 64 + 8) * 8 + ONE_CB_CHUNK / 8 + 8; }
 inline bool one_supported(int K, int R) { return K >= 2 && K <= 7 && R >= 1 && R <= 8; }
 
 template <int SHIFT>
 inline int one_launch_update(int R, const OneUpdateArgs& a, hipStream_t st) {
+    if (one_update7_supported(a.K, R)) {
+        switch (R) {
+            case 1: hipLaunchKernelGGL((one_update7_kernel<1, SHIFT>), dim3(1), dim3(192), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((one_update7_kernel<2, SHIFT>), dim3(1), dim3(192), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((one_update7_kernel<3, SHIFT>), dim3(1), dim3(192), 0, st, a); break;
+            default: hipLaunchKernelGGL((one_update7_kernel<4, SHIFT>), dim3(1), dim3(192), 0, st, a); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     switch (R) {
         case 1: hipLaunchKernelGGL((one_update_kernel<1, SHIFT>), dim3(1), dim3(64), 0, st, a); break;
         case 2: hipLaunchKernelGGL((one_update_kernel<2, SHIFT>), dim3(1), dim3(64), 0, st, a); break;
@@ -332,6 +675,19 @@ inline int one_launch_frame(int R, const OneFrameArgs& a, hipStream_t st) {
         if (smem > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(one_frame_kernel<r, SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1; \
         hipLaunchKernelGGL((one_frame_kernel<r, SHIFT>), dim3(1), dim3(64), smem, st, a);                                                  \
         break;
+#define VIT_ONE_FRAME7_CASE(r)                                                                                                             \
+    case r:                                                                                                                                \
+        if (smem > 32 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(one_frame7_kernel<r, SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1; \
+        hipLaunchKernelGGL((one_frame7_kernel<r, SHIFT>), dim3(1), dim3(192), smem, st, a);                                                \
+        break;
+    if (one_update7_supported(a.u.K, R)) {
+        switch (R) {
+            VIT_ONE_FRAME7_CASE(1) VIT_ONE_FRAME7_CASE(2) VIT_ONE_FRAME7_CASE(3) VIT_ONE_FRAME7_CASE(4)
+            default: return -1;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+#undef VIT_ONE_FRAME7_CASE
     switch (R) {
         VIT_ONE_FRAME_CASE(1) VIT_ONE_FRAME_CASE(2) VIT_ONE_FRAME_CASE(3) VIT_ONE_FRAME_CASE(4)
         VIT_ONE_FRAME_CASE(5) VIT_ONE_FRAME_CASE(6) VIT_ONE_FRAME_CASE(7) VIT_ONE_FRAME_CASE(8)
