@@ -506,6 +506,10 @@ def dry_run(args, world, rank, affinity):
 
 
 def host_route(args):
+    print(json.dumps(host_route_result(args)))
+
+
+def host_route_result(args):
     """BASELINE configs[0]: one frame through the drop-in's own call pattern (examples/run_simple.cpp:67-80) -- a single decoder
     object with the reference's public state; update() runs ONE GPU launch that also chains the completed frame back
     (vit_hip_update_host_lazy: symbols read from host-mapped memory, rows kept on the device, results polled), chainback() then
@@ -569,7 +573,9 @@ def host_route(args):
         "dtype": "u16" if pc.error_bytes == 2 else "u8", "data": "synthetic",
         "config": {"workload": f"{code.name} K={code.K} R=1/{code.R} {args.decode_type}, ONE frame of {L} info bits through the header-level drop-in "
                                f"(ViterbiDecoder_HIP::update + ViterbiDecoder_Core::chainback, host-resident state), AWGN Eb/N0={args.ebn0} dB",
-                   "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": "one wavefront, lane == state; update + the chainback behind it in ONE launch, rows kept on the device (csrc/kernels_one.hpp: one_frame_kernel)" if code.K <= 7 else "lds"},
+                   "frames_per_gpu": 1, "bits_per_frame": L, "via": "host", "plan": ("in-place trellis on one wavefront + two helper wavefronts (csrc/kernels_one.hpp: one_frame7_kernel)" if code.K == 7 and code.R <= 4
+                            else "one wavefront, lane == state (csrc/kernels_one.hpp: one_frame_kernel)" if code.K <= 7 else "lds")
+                           + "; update + the chainback behind it in ONE launch, rows kept on the device"},
         "update_ms": float(np.median(t_upd)) * 1e3, "chainback_ms": float(np.median(t_cb)) * 1e3,
         "ms_per_step_median": float(np.median(np.asarray(t_upd) + np.asarray(t_cb))) * 1e3,
         # the spread of the two calls themselves (a step's reset() and the loop around them are the rest of ms_per_step)
@@ -601,7 +607,7 @@ def host_route(args):
                                   "simd_1thread_Mbit_s": res.get("avx"), "ms_per_frame_scalar": L / res["scalar"] / 1e3 if res.get("scalar") else None,
                                   "ms_per_frame_avx": L / res["avx"] / 1e3 if res.get("avx") else None, "host": {k: v for k, v in topo.items() if k != "cpus"}}
         result["speedup_vs_cpu_baseline"] = result["value"] / res["scalar"] if res.get("scalar") else None
-    print(json.dumps(result))
+    return result
 
 
 def main():
@@ -1133,6 +1139,19 @@ def main():
                 extra.append(run_case(idx, args.steps, args.warmup, local_rank, dev, sustain_seconds=min(1.0, args.sustain_seconds)))
             except Exception as e:
                 extra.append({"baseline_config": idx, "error": f"{type(e).__name__}: {e}"})
+        # ... and configs[0], the reference's own first example (examples/run_simple.cpp): ONE 4096-bit frame through the drop-in's
+        # reset -> update -> chainback (a latency figure; `--config 0` prints the same record alone)
+        try:
+            import argparse
+            t0c = time.perf_counter()
+            c0 = BASELINE_CONFIGS[0]
+            r0 = host_route_result(argparse.Namespace(code=c0[0], decode_type=c0[1], bits=c0[3], ebn0=c0[4], steps=max(args.steps, 200), warmup=max(args.warmup, 20),
+                                                      no_cpu_baseline=args.no_cpu_baseline))
+            r0["baseline_config"] = 0
+            r0["seconds_spent"] = time.perf_counter() - t0c
+            extra.insert(0, r0)
+        except Exception as e:
+            extra.insert(0, {"baseline_config": 0, "error": f"{type(e).__name__}: {e}"})
         result["configs"] = extra
     print(json.dumps(result))
     if world > 1:

