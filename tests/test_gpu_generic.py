@@ -139,11 +139,14 @@ def test_generic_kernels_rate(oracle, monkeypatch, tmp_path, K, G, stock_id, flo
         for _ in range(n_warm):
             pipe.submit(sym, out)
         pipe.sync()
-        t0 = time.perf_counter()
-        for _ in range(n_timed):
-            pipe.submit(sym, out)
-        pipe.sync()
-        rates[name] = n_timed * F * L / (time.perf_counter() - t0) / 1e9
+        best = 0.0
+        for _ in range(3):                      # the best of three timed loops: one slow step of the box must not decide a ratio
+            t0 = time.perf_counter()
+            for _ in range(n_timed):
+                pipe.submit(sym, out)
+            pipe.sync()
+            best = max(best, n_timed * F * L / (time.perf_counter() - t0) / 1e9)
+        rates[name] = best
         if name == "generic":
             n = 64
             want, _, _ = oracle.decode_frames(K, 2, code.G, oracle_cfg("SOFT16", 2), sym[:n].cpu().numpy(), L, threads=8)
