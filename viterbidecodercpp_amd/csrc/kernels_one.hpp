@@ -328,6 +328,9 @@ __device__ __forceinline__ void one_update7_body(const OneUpdateArgs& a) {
             }
             // decision = u > v (tie -> 0, :123-124) straight into the history word (hist = 2 hist + carry), new metric = the smaller (:127-128)
             uint32_t &hs = hist, &mm = m, &mm2 = m2;
+            // (order inside the asm: hipcc cannot see into it, and on gfx940+ a vector instruction that reads VCC wants two
+            // instructions between itself and the one that wrote it -- the two minima are those; what FOLLOWS the block hipcc pads
+            // itself: it puts s_nop 1 in front of a DPP move or lane swap that reads the block's outputs)
             asm volatile("v_cmp_gt_u16 vcc, %3, %4\n\tv_min_u16 %1, %3, %4\n\tv_min_u16 %2, %3, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                          : "+v"(hs), "=&v"(mm), "=&v"(mm2) : "v"(u), "v"(v) : "vcc");
             // the other lanes compare against a value no metric reaches: one v_cmp into a scalar pair, branched on one step later
