@@ -28,3 +28,16 @@ def test_soak_slice():
     print(f"soak slice: first seed {first_seed} (re-run with VIT_SOAK_SEED={first_seed})")
     n = soak(45.0, first_seed)
     assert n >= 200, (n, first_seed)
+
+
+@pytest.mark.timeout(300)
+def test_host_route_soak_slice():
+    """the single-decoder host route (one frame: the in-place K = 7 kernel with its helper wavefronts, the lane == state kernel for the
+    other K <= 7 codes) under tests/soak_host_route.py's random polynomials, configurations, symbols and call splits: a fixed-seed and
+    a date-seeded slice (VIT_SOAK_SEED re-runs one)"""
+    from tests.soak_host_route import soak
+
+    assert soak(10.0, 31337) >= 500
+    first_seed = int(os.environ.get("VIT_SOAK_SEED", 200000 + int(time.time() // 86400) % 100000))
+    print(f"host-route soak slice: first seed {first_seed} (re-run with VIT_SOAK_SEED={first_seed})")
+    assert soak(15.0, first_seed) >= 800, first_seed
