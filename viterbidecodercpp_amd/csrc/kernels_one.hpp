@@ -344,29 +344,35 @@ __device__ __forceinline__ void one_update7_body(const OneUpdateArgs& a) {
                     constexpr int QD = 4;                        // table rows in flight (2, 4, 8: the same step time)
                     uint2 q[QD];
                     one_static_for<QD>([&](auto dc) __attribute__((always_inline)) { q[decltype(dc)::value] = fetch(std::integral_constant<int, bb * BLK + decltype(dc)::value>{}); });
-                    // can state 0 reach the threshold inside this block?  (whole blocks only; a threshold of 0 -- "always" -- never passes)
-                    bool safe = false;
-                    if (nb == BLK) {
-                        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-                        const uint32_t em = (uint32_t)__builtin_amdgcn_readfirstlane((int)one_emax[bb]);
-                        safe = m0 + (uint32_t)BLK * em < threshold;
-                    }
                     auto one = [&](auto kc, auto testc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         const uint2 bm = q[k % QD];
                         if constexpr (k + QD < BLK) q[k % QD] = fetch(std::integral_constant<int, bb * BLK + k + QD>{});   // (rows of THIS block only: the next one's appear behind the barrier)
                         step(std::integral_constant<int, bb * BLK + k>{}, testc, bm);
                     };
-                    if (safe) {
-                        one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { one(kc, std::false_type{}); });
+                    if (nb == BLK) {
+                        // can state 0 reach the threshold inside the next GRP steps?  (m[0] + GRP x the block's largest branch metric against
+                        // the threshold; a threshold of 0 -- "always" -- never passes.)  Decided once per block: groups of 16 or 8 pass the
+                        // test more often -- with the reference's 8-bit soft configuration 32 steps' worth of the bound never fits under
+                        // the threshold -- but the decision itself (v_readfirstlane -> scalar compare -> branch, and settling the last
+                        // test at the end of every tested group) costs what they save: 8192-bit frames, same box, GRP = 32 / 16 / 8:
+                        // Voyager SOFT16 273 / 278 / 288 us, SOFT8 318 / 326 / 326, DAB SOFT8 367 / 382 / 404
+                        constexpr int GRP = 32;
+                        const uint32_t em = (uint32_t)__builtin_amdgcn_readfirstlane((int)one_emax[bb]);
+                        one_static_for<BLK / GRP>([&](auto gc) __attribute__((always_inline)) {
+                            constexpr int g0 = decltype(gc)::value * GRP;
+                            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+                            if (m0 + (uint32_t)GRP * em < threshold) {
+                                one_static_for<GRP>([&](auto kc) __attribute__((always_inline)) { one(std::integral_constant<int, g0 + decltype(kc)::value>{}, std::false_type{}); });
+                            } else {
+                                one_static_for<GRP>([&](auto kc) __attribute__((always_inline)) { one(std::integral_constant<int, g0 + decltype(kc)::value>{}, std::true_type{}); });
+                                // the group's last test is settled here (every group starts with nothing pending)
+                                if (pend != 0) { renormalise(); m2 = m; pend = 0; }
+                            }
+                        });
                     } else {
-                        if (nb == BLK) {
-                            one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { one(kc, std::true_type{}); });
-                        } else {
-                            one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { if (decltype(kc)::value < nb) one(kc, std::true_type{}); });
-                            hist <<= (BLK - nb);           // the block's first step at bit 31
-                        }
-                        // the block's last test is settled here (every block starts with nothing pending)
+                        one_static_for<BLK>([&](auto kc) __attribute__((always_inline)) { if (decltype(kc)::value < nb) one(kc, std::true_type{}); });
+                        hist <<= (BLK - nb);           // the block's first step at bit 31
                         if (pend != 0) { renormalise(); m2 = m; pend = 0; }
                     }
                     one_hist[(b0 + bb) & 1][lane] = hist;
