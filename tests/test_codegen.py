@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 import subprocess
+import time
 
 import pytest
 
@@ -46,6 +47,8 @@ def _compile(src, defines, tmp_path):
     if os.path.exists(c_asm) and os.path.exists(c_err) and not os.environ.get("VIT_TEST_NO_CODEGEN_CACHE"):
         stderr = open(c_err).read()
         out.write_text(open(c_asm).read())
+        os.utime(c_asm, None)                   # a live entry stays young: the sweep below drops what no run has used for two days
+        os.utime(c_err, None)
     else:
         p = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -54,6 +57,10 @@ def _compile(src, defines, tmp_path):
         shutil.copyfile(str(out), c_asm + ".tmp")
         os.replace(c_asm + ".tmp", c_asm)
         open(c_err, "w").write(stderr)
+        for f in os.listdir(cache):             # entries of sources that no longer exist (the key holds their digest): 2 MB each
+            path = os.path.join(cache, f)
+            if time.time() - os.path.getmtime(path) > 2 * 86400:
+                os.unlink(path)
     usage = {}
     name = None
     for line in stderr.splitlines():
