@@ -29,6 +29,11 @@ COMMON_SETS = [
     ("GSM K=5 R=1/2", 5, 2, (0o23, 0o33)),
     ("UMTS / LTE-CC K=9 R=1/2", 9, 2, (0o561, 0o753)),
     ("UMTS K=9 R=1/3", 9, 3, (0o557, 0o663, 0o711)),
+    # the textbook maximum-free-distance sets below K = 7 (K >= 7: the GENERIC kernels serve whatever comes): seconds of hipcc each
+    ("best K=3 R=1/2", 3, 2, (0o5, 0o7)), ("best K=3 R=1/3", 3, 3, (0o5, 0o7, 0o7)),
+    ("best K=4 R=1/2", 4, 2, (0o15, 0o17)), ("best K=4 R=1/3", 4, 3, (0o13, 0o15, 0o17)),
+    ("best K=5 R=1/2", 5, 2, (0o23, 0o35)), ("best K=5 R=1/3", 5, 3, (0o25, 0o33, 0o37)),
+    ("best K=6 R=1/2", 6, 2, (0o53, 0o75)), ("IS-54 / IS-136 K=6 R=1/2", 6, 2, (0o65, 0o57)),
     # all polynomials zero: the GENERIC kernels of (K, R) -- polynomials read at run time, one code object for every set (what
     # vit_hip_create falls back to when neither the library nor this cache holds kernels specialised for a set)
 ]
