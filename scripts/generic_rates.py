@@ -15,6 +15,11 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 
 # (K, R, polynomials nobody compiled, polynomials with specialised kernels, where those come from)
 CASES = [
+    (3, 2, (0o7, 0o7), (0o7, 0o5), "stock Basic K=3"),
+    (4, 2, (0o13, 0o17), (0o15, 0o17), "package cache (best K=4)"),
+    (5, 2, (0o37, 0o21), (0o27, 0o31), "stock Basic K=5"),
+    (5, 3, (0o27, 0o31, 0o35), (0o25, 0o33, 0o37), "package cache (best K=5 R=1/3)"),
+    (6, 2, (0o73, 0o45), (0o65, 0o57), "package cache (IS-54)"),
     (7, 2, (0o147, 0o135), (0o155, 0o117), "stock Voyager"),
     (7, 3, (0o133, 0o145, 0o175), (0o133, 0o171, 0o165), "stock LTE"),
     (7, 4, (0o117, 0o133, 0o155, 0o171), (0o155, 0o117, 0o123, 0o155), "stock DAB (8 of 16 patterns occur)"),

@@ -34,6 +34,10 @@ SETS = [
     # K = 8, 9: the sub-chunk fetch (a butterfly's pair arrives one sub-chunk of four butterflies ahead)
     (9, 2, (0o515, 0o677)), (9, 2, (0o401, 0o777)), (9, 3, (0o435, 0o567, 0o715)), (9, 4, (0o463, 0o535, 0o733, 0o745)),
     (8, 2, (0o247, 0o371)), (8, 3, (0o225, 0o331, 0o367)), (8, 4, (0o235, 0o275, 0o313, 0o357)),
+    # below K = 7: all states of a frame pair in one lane, the 2^R pairs parked in LDS and read back per butterfly
+    (5, 2, (0o37, 0o21)), (5, 3, (0o27, 0o31, 0o35)), (5, 4, (0o25, 0o27, 0o33, 0o37)),
+    (6, 2, (0o73, 0o45)), (6, 4, (0o53, 0o67, 0o71, 0o75)), (4, 2, (0o13, 0o17)), (4, 3, (0o11, 0o15, 0o17)), (4, 4, (0o13, 0o15, 0o15, 0o17)),
+    (3, 2, (0o7, 0o7)), (3, 3, (0o5, 0o5, 0o7)), (3, 4, (0o5, 0o7, 0o7, 0o7)),
 ]
 
 
@@ -46,8 +50,9 @@ def test_generic_kernels_match_oracle(oracle, monkeypatch, tmp_path, K, R, G, de
     code = Code(f"K{K}R{R}", K, R, G)
     ebn0 = {"SOFT16": 2.0, "SOFT8": 3.0, "HARD8": 4.0}[decode_type]
     pc, _, _ = make_table_config(code, decode_type)
-    _, sym = synth.make_frames_numpy(code, pc, 70, 432, ebn0, seed=sum(G) + R)
-    dec = check_batch_against_oracle(oracle, code, decode_type, 70, 427, ebn0, seed=0, sym=sym)     # plan=None: PLAN_AUTO
+    F = 70 if K >= 7 else 150                   # (below K = 7 a wavefront holds 128 frames)
+    _, sym = synth.make_frames_numpy(code, pc, F, 432, ebn0, seed=sum(G) + R)
+    dec = check_batch_against_oracle(oracle, code, decode_type, F, 427, ebn0, seed=0, sym=sym)     # plan=None: PLAN_AUTO
     assert dec.plan == _lib.PLAN_REG, dec.plan_note
     assert "GENERIC" in dec.plan_note and "_0_0_0_0_0_0_" in dec.plan_note and "package cache" in dec.plan_note, dec.plan_note
     assert not any(f.endswith(".hsaco") for f in os.listdir(tmp_path))          # nothing was compiled
@@ -56,7 +61,9 @@ def test_generic_kernels_match_oracle(oracle, monkeypatch, tmp_path, K, R, G, de
 @pytest.mark.parametrize("K,R,G,width", [(7, 2, (0o147, 0o135), 2), (7, 2, (0o165, 0o127), 1), (7, 3, (0o133, 0o145, 0o175), 2),
                                          (7, 4, (0o117, 0o133, 0o155, 0o171), 1), (7, 4, (0o135, 0o135, 0o147, 0o163), 2),
                                          (9, 2, (0o515, 0o677), 2), (9, 3, (0o435, 0o567, 0o715), 1), (9, 4, (0o463, 0o535, 0o733, 0o745), 2),
-                                         (8, 2, (0o247, 0o371), 1), (8, 3, (0o225, 0o331, 0o367), 2)])
+                                         (8, 2, (0o247, 0o371), 1), (8, 3, (0o225, 0o331, 0o367), 2),
+                                         (5, 2, (0o37, 0o21), 2), (5, 3, (0o27, 0o31, 0o35), 1), (6, 2, (0o73, 0o45), 2), (6, 4, (0o53, 0o67, 0o71, 0o75), 1),
+                                         (4, 3, (0o11, 0o15, 0o17), 2), (3, 2, (0o7, 0o7), 1)])
 def test_generic_kernels_resume_and_states(oracle, monkeypatch, tmp_path, K, R, G, width):
     """batched streaming (vit_hip_update_batch_resume enters the unrolled block in the middle: the offset-table rows in flight must
     belong to the steps that follow), non-zero start / end states, and a threshold state 0 crosses every two to six steps -- chunks
@@ -69,7 +76,7 @@ def test_generic_kernels_resume_and_states(oracle, monkeypatch, tmp_path, K, R, 
 
     _no_compiler(monkeypatch, tmp_path)
     code = Code(f"K{K}R{R}", K, R, G)
-    F, L = 45, 150
+    F, L = (45 if K >= 7 else 150), 150          # (below K = 7 a wavefront holds 128 frames)
     S = L + K - 1
     rng = np.random.default_rng(4300 + R + width)
     if width == 2:

@@ -133,7 +133,7 @@ struct RegSpec {
     // steps ahead (two ds_read_b128 at K = 7), ORs the lane's pair offset in (NREG / 2 two-pass-free v_or_b32) and issues NREG / 2
     // ds_read_b64 instead of 2^R.  The producer writes entry P at index P (bm_index is the identity for zero polynomials).
     static constexpr bool GENERIC = G0 == 0 && G1 == 0 && G2 == 0 && G3 == 0 && G4 == 0 && G5 == 0;
-    static_assert(!GENERIC || (LANE_BITS_ == 2 && R_ <= 4), "generic kernels: the LDS-ring geometries (K >= 7) with whole patterns (R <= 4)");
+    static_assert(!GENERIC || R_ <= 4, "generic kernels: whole patterns (R <= 4)");
     // LANE_BITS = 2: two state-slot bits live in the lane index (lane bits 4 and 5), 16 frame pairs per wave;
     // LANE_BITS = 0 (small K): every state of a frame pair lives in ONE lane's registers, 64 frame pairs per wave
     static constexpr int LANE_BITS = LANE_BITS_;
@@ -451,7 +451,11 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     static_assert(!LDSBM || (BPS <= 12 && (U / GROUP) % NG == 0 && U % RING == 0), "LDSBM geometry");
     constexpr int ROW = NPROW * 16;               // uint2 {E, EB} entries per step: [pattern (SPLIT: low part, then high part)][pair g]
     __shared__ uint2 bm_ring[LDSBM ? RING * ROW : 1];
-    static_assert(!GENERIC || (LDSBM && !SPLIT && NH % 4 == 0 && (!BMCHUNK || RC::CS == 4)), "generic kernels: whole patterns from the LDS ring");
+    static_assert(!GENERIC || (!SPLIT && NH >= 2 && (!BMCHUNK || RC::CS == 4)), "generic kernels: whole patterns");
+    // GENERIC below K = 7 (all states of a pair in one lane, no ring): the lane parks the 2^R pairs it has just formed in LDS,
+    // [step parity][pattern][lane], and every butterfly reads its own back through the same run-time offsets (pattern x 512 bytes)
+    __shared__ uint2 gen_bm[GENERIC && !LDSBM ? 2 * NP * 64 : 1];
+    constexpr int GEN_SHIFT = LDSBM ? 7 : 9;       // a table entry: pattern x (pairs of a row x 8 bytes)
     // GENERIC: ring byte offset of the entry butterfly h of lane group q reads in layout step UP: [UP][q][h], filled below
     __shared__ __attribute__((aligned(16))) u32 gen_tab[GENERIC ? PER * 4 * NH : 4];
     constexpr u32 BIAS2 = 0x80008000u;   // metrics are kept as (m ^ 0x8000): unsigned order == signed order of the biased value
@@ -649,6 +653,28 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
     static_assert(RC::NSUB % NEB == 0 || !BMCHUNK, "buffer index = sub-chunk % NEB in every step");
     u32 Ec[NEB][RC::CS], EBc[NEB][RC::CS];       // BMCHUNK: [sub-chunk % NEB][slot]
     u32 Hc[NEB][SPLIT ? RC::CS : 1];             // ... SPLIT: the high parts (Ec / EBc then hold the low parts)
+    // GENERIC: the offset table and the two rows in flight
+    u32 TG[2][!GENERIC ? 1 : BMCHUNK ? RC::CS : NH];
+    const u32 g8 = g * 8u;
+    const u32* gen_mine = gen_tab + q * NH;        // this lane group's rows
+    // BMCHUNK: the four offsets of sub-chunk s of block step un, into TG[s & 1] (sub-chunks are fetched in order, two rows in flight)
+    auto gen_chunk_row = [&](auto unc, auto sc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value, s = decltype(sc)::value, UPn = (un % U) % PER;
+        const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * s);
+        TG[s & 1][0] = v.x; TG[s & 1][1] = v.y; TG[s & 1][2] = v.z; TG[s & 1][3] = v.w;
+    };
+    auto gen_row = [&](auto unc) __attribute__((always_inline)) {
+        constexpr int un = decltype(unc)::value, UPn = (un % U) % PER;
+        if constexpr (NH % 4 == 0) {
+            static_for<NH / 4>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * k);
+                TG[un & 1][4 * k] = v.x; TG[un & 1][4 * k + 1] = v.y; TG[un & 1][4 * k + 2] = v.z; TG[un & 1][4 * k + 3] = v.w;
+            });
+        } else {
+            static_for<NH>([&](auto kc) __attribute__((always_inline)) { TG[un & 1][decltype(kc)::value] = gen_mine[UPn * 4 * NH + decltype(kc)::value]; });   // K = 3: two butterflies
+        }
+    };
     auto branch_metrics = [&](auto unc) __attribute__((always_inline)) {
         if constexpr (!LDSBM) {
         constexpr int un = decltype(unc)::value;
@@ -677,9 +703,25 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 constexpr int i = decltype(ic)::value + 1;
                 e = pk_add(e, ((p >> i) & 1) ? A1[i] : A0[i]);
             });
-            E[buf][p] = e;
-            EB[buf][p] = pk_sub(MAXE2, e);
+            if constexpr (GENERIC) gen_bm[(buf * NP + p) * 64 + lane] = make_uint2(e, pk_sub(MAXE2, e));
+            else {
+                E[buf][p] = e;
+                EB[buf][p] = pk_sub(MAXE2, e);
+            }
         });
+        if constexpr (GENERIC) {
+            // one wavefront per workgroup, LDS operations complete in order: the reads below see the pairs just written
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            static_for<NH>([&](auto hc) __attribute__((always_inline)) {
+                constexpr int h = decltype(hc)::value;
+                const uint2 v = *(const uint2*)((const char*)gen_bm + (TG[buf][h] | g8) + buf * NP * 512);
+                E[buf][h] = v.x;
+                EB[buf][h] = v.y;
+            });
+            gen_row(std::integral_constant<int, un + 2>{});
+        }
         }
     };
     static_assert(U % 2 == 0, "E double buffer alternates per step");
@@ -751,24 +793,6 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
         constexpr u32 tp = SP::bm_index(PHn, pv, off, nb);
         return (const char*)bm_ring + bm_rd[f][tp & ((1u << w) - 1u)] + (((tp >> w) << w) << 7) + base * 128 + (us % RING) * ROW * 8;
     };
-    // GENERIC: the offset table and the two rows in flight
-    u32 TG[2][!GENERIC ? 1 : BMCHUNK ? RC::CS : NH];
-    const u32 g8 = g * 8u;
-    const u32* gen_mine = gen_tab + q * NH;        // this lane group's rows
-    // BMCHUNK: the four offsets of sub-chunk s of block step un, into TG[s & 1] (sub-chunks are fetched in order, two rows in flight)
-    auto gen_chunk_row = [&](auto unc, auto sc) __attribute__((always_inline)) {
-        constexpr int un = decltype(unc)::value, s = decltype(sc)::value, UPn = (un % U) % PER;
-        const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * s);
-        TG[s & 1][0] = v.x; TG[s & 1][1] = v.y; TG[s & 1][2] = v.z; TG[s & 1][3] = v.w;
-    };
-    auto gen_row = [&](auto unc) __attribute__((always_inline)) {
-        constexpr int un = decltype(unc)::value, UPn = (un % U) % PER;
-        static_for<NH / 4>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value;
-            const uint4 v = *(const uint4*)(gen_mine + UPn * 4 * NH + 4 * k);
-            TG[un & 1][4 * k] = v.x; TG[un & 1][4 * k + 1] = v.y; TG[un & 1][4 * k + 2] = v.z; TG[un & 1][4 * k + 3] = v.w;
-        });
-    };
     if constexpr (GENERIC) {
         // pat(v): bit i = parity((v << 1) & G[i])  (viterbi_branch_table.h:48-51), with the polynomials of the kernel arguments
         auto pat_rt = [&](u32 v) __attribute__((always_inline)) -> u32 {
@@ -796,7 +820,7 @@ VIT_DEV void reg_update_body(const RegUpdateArgs& a) {
                 if ((qq >> lb) & 1u) x |= 1u << T;
                 if ((qq >> (1 - lb)) & 1u) x |= 1u << (REG_BITS + (1 - lb));
             }
-            gen_tab[e] = (pat_rt(SP::rotl(r0, ph)) ^ pat_rt(SP::rotl(x, ph))) << 7;
+            gen_tab[e] = (pat_rt(SP::rotl(r0, ph)) ^ pat_rt(SP::rotl(x, ph))) << GEN_SHIFT;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2019,8 +2043,12 @@ struct RegCode {
     bool generic = false;   // jit is the GENERIC code object of (K, R): the kernels read G from their arguments (RegSpec::GENERIC)
 };
 
-// (K, R) with a generic register-plan kernel: the LDS-ring geometries (K = 7: whole-step fetch, K = 8, 9: per sub-chunk) at whole patterns
-inline bool reg_generic_supported(int K, int R) { return K >= 7 && K <= 9 && R >= 2 && R <= 4; }
+// (K, R) with a generic register-plan kernel: the LDS-ring geometries (K = 7: whole-step fetch, K = 8, 9: per sub-chunk) and, below K = 7,
+// the one-lane geometry with the pairs parked in LDS; whole patterns (R <= 4)
+inline bool reg_generic_supported(int K, int R) {
+    // (K = 6 at an odd rate unrolls a 240-step block: two minutes of hipcc per object; K = 2: one butterfly, nothing to look up)
+    return K >= 3 && K <= 9 && R >= 2 && R <= 4 && !(K == 6 && R == 3);
+}
 
 inline bool reg_code_supported(int K, int R) {
     return (K == 7 && R >= 2 && R <= 4) || (K == 9 && (R == 2 || R == 4)) || ((K == 3 || K == 5) && R == 2);

@@ -457,7 +457,7 @@ const char* vit_hip_plan_note(vit_hip_handle h) {
         const bool pkg = h->reg_origin.compare(0, vit::package_cache_dir().size(), vit::package_cache_dir()) == 0;
         note += std::string(pkg ? "; kernels precompiled at install time, loaded from the package cache " : "; kernels compiled at run time, loaded from the user cache ") + h->reg_origin;
         if (h->reg_code.generic)
-            note += "; these are the GENERIC kernels of this (K, R) -- polynomials read at run time, about 5 % behind kernels specialised for them: "
+            note += "; these are the GENERIC kernels of this (K, R) -- polynomials read at run time, 2 - 20 % behind kernels specialised for them: "
                     "python -m viterbidecodercpp_amd.tools.precompile K R G... at install time, or VIT_HIP_JIT=1 before vit_hip_create (hipcc), gets those";
     }
     if (h->plan == VIT_HIP_PLAN_LDS) {
@@ -1627,7 +1627,7 @@ static int vit_hip_precompile_impl(int K, int R, const uint32_t* polynomials, in
     bool generic = true;
     for (int i = 0; i < R; ++i) generic = generic && polynomials[i] == 0;
     if (generic) {
-        if (!vit::reg_generic_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "generic register-plan kernels exist for K = 7..9 with R = 2..4");
+        if (!vit::reg_generic_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "generic register-plan kernels exist for K = 3..9 with R = 2..4 (not K = 6 at R = 3)");
         for (int i = 0; i < R; ++i) G[i] = 0;
     }
     std::string err;
