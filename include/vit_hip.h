@@ -122,7 +122,7 @@ int vit_hip_set_plan(vit_hip_handle h, int plan);
  * Needs hipcc ($VIT_HIP_HIPCC, else /opt/rocm/bin/hipcc) and the kernel sources beside the library, but NO GPU: a build host
  * without a card can run it (python -m viterbidecodercpp_amd.tools.precompile does, for a list of common sets, from build()).
  * An object that already exists is kept.  path_out (optional) receives the file's path.  K = 2..9, R <= 6.
- * ALL polynomials zero names the GENERIC kernels of (K, R) (K = 3 .. 9 with R = 2, 3, 4; not K = 6 at R = 3): one code object that reads the
+ * ALL polynomials zero names the GENERIC kernels of (K, R) (K = 3 .. 9 with R = 1 .. 4; not K = 6 at an odd rate): one code object that reads the
  * polynomials from its arguments at run time, as the reference's branch table does -- 0.79 - 0.98 of the specialised kernels' rate.  build()
  * installs them, and vit_hip_create falls back to them (PLAN_AUTO included) for every set of those (K, R) that has neither built-in nor
  * precompiled kernels: no such code drops to the compatibility plan on a host without a compiler.  vit_hip_plan_note says "GENERIC". */

@@ -218,7 +218,7 @@ def test_plan_reg_runtime_instantiation(oracle, K, R, G, decode_type):
     # that were precompiled into the package at install time (tools/precompile.py: COMMON_SETS)
     from viterbidecodercpp_amd.tools.precompile import COMMON_SETS
     in_package = any((K, R, tuple(G)) == (k, r, g) for _, k, r, g in COMMON_SETS)
-    generic = 3 <= K <= 9 and 2 <= R <= 4 and (K, R) != (6, 3)       # ... or, for these (K, R), the package's GENERIC kernels (tests/test_gpu_generic.py)
+    generic = 3 <= K <= 9 and 1 <= R <= 4 and not (K == 6 and R % 2)       # ... or, for these (K, R), the package's GENERIC kernels (tests/test_gpu_generic.py)
     auto = BatchDecoder(table, config)
     assert auto.plan == (_lib.PLAN_REG if in_package or generic else _lib.PLAN_LDS)
     assert ("GENERIC" in auto.plan_note) == (generic and not in_package), auto.plan_note
@@ -274,7 +274,7 @@ def test_plan_reg_runtime_instantiation_failure_is_an_error_code(monkeypatch, tm
     assert b"hipcc" in msg, msg
     dec._handle.refresh()
     assert dec.plan == _lib.PLAN_LDS                                  # still usable on the LDS plan
-    # K = 3..9, R = 2..4: the handle already runs the package's GENERIC kernels; the failed attempt at specialised ones leaves them in place
+    # K = 3..9, R = 1..4: the handle already runs the package's GENERIC kernels; the failed attempt at specialised ones leaves them in place
     pc, table, config = make_table_config(Code("custom", 7, 2, (0o147, 0o135)), "SOFT16")
     dec = BatchDecoder(table, config)
     assert dec.plan == _lib.PLAN_REG and "GENERIC" in dec.plan_note
@@ -303,7 +303,7 @@ def test_precompiled_package_cache_serves_plan_reg_without_a_compiler(oracle, mo
         assert dec.plan == _lib.PLAN_REG, dec.plan_note
         assert "package cache" in dec.plan_note and "/precompiled/reg_K" in dec.plan_note, dec.plan_note
     assert not any(f.endswith(".hsaco") for f in os.listdir(tmp_path))          # nothing was compiled
-    # a set that was NOT precompiled runs the package's GENERIC kernels where (K, R) has them (K = 3..9, R = 2..4: tests/test_gpu_generic.py)
+    # a set that was NOT precompiled runs the package's GENERIC kernels where (K, R) has them (K = 3..9, R = 1..4: tests/test_gpu_generic.py)
     # and stays on the compatibility plan where not
     pc, table, config = make_table_config(Code("custom", 7, 2, (0o147, 0o135)), "SOFT16")
     d = BatchDecoder(table, config)

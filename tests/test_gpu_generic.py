@@ -38,6 +38,8 @@ SETS = [
     (5, 2, (0o37, 0o21)), (5, 3, (0o27, 0o31, 0o35)), (5, 4, (0o25, 0o27, 0o33, 0o37)),
     (6, 2, (0o73, 0o45)), (6, 4, (0o53, 0o67, 0o71, 0o75)), (4, 2, (0o13, 0o17)), (4, 3, (0o11, 0o15, 0o17)), (4, 4, (0o13, 0o15, 0o15, 0o17)),
     (3, 2, (0o7, 0o7)), (3, 3, (0o5, 0o5, 0o7)), (3, 4, (0o5, 0o7, 0o7, 0o7)),
+    # rate 1 (no redundancy, but a valid trellis: one symbol per step, two branch patterns)
+    (7, 1, (0o165,)), (9, 1, (0o753,)), (5, 1, (0o27,)), (8, 1, (0o371,)),
 ]
 
 

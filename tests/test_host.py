@@ -184,9 +184,10 @@ def test_precompile_writes_a_code_object_without_a_gpu(tmp_path):
     G = (C.c_uint32 * 6)(0o1167, 0o1545)
     assert lib.vit_hip_precompile(10, 2, G, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_precompile(7, 2, G, 4, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
-    # all polynomials zero names the GENERIC kernels of (K, R) (polynomials read at run time): K = 3..9 with R = 2..4 (not K = 6 at R = 3)
+    # all polynomials zero names the GENERIC kernels of (K, R) (polynomials read at run time): K = 3..9 with R = 1..4 (not K = 6 at an odd rate)
     Z = (C.c_uint32 * 6)()
     assert lib.vit_hip_precompile(6, 3, Z, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
+    assert lib.vit_hip_precompile(6, 1, Z, 1, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_precompile(2, 2, Z, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     assert lib.vit_hip_precompile(7, 5, Z, 2, str(tmp_path).encode(), None, 0) == _lib.ERR_UNSUPPORTED
     # the package cache build() fills: every common set, both widths, compiled from the CURRENT kernel sources

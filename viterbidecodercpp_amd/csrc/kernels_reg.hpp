@@ -2046,8 +2046,8 @@ struct RegCode {
 // (K, R) with a generic register-plan kernel: the LDS-ring geometries (K = 7: whole-step fetch, K = 8, 9: per sub-chunk) and, below K = 7,
 // the one-lane geometry with the pairs parked in LDS; whole patterns (R <= 4)
 inline bool reg_generic_supported(int K, int R) {
-    // (K = 6 at an odd rate unrolls a 240-step block: two minutes of hipcc per object; K = 2: one butterfly, nothing to look up)
-    return K >= 3 && K <= 9 && R >= 2 && R <= 4 && !(K == 6 && R == 3);
+    // (K = 6 at an odd rate unrolls an 80- to 240-step block: minutes of hipcc per object; K = 2: one butterfly, nothing to look up)
+    return K >= 3 && K <= 9 && R >= 1 && R <= 4 && !(K == 6 && (R & 1));
 }
 
 inline bool reg_code_supported(int K, int R) {

@@ -1627,7 +1627,7 @@ static int vit_hip_precompile_impl(int K, int R, const uint32_t* polynomials, in
     bool generic = true;
     for (int i = 0; i < R; ++i) generic = generic && polynomials[i] == 0;
     if (generic) {
-        if (!vit::reg_generic_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "generic register-plan kernels exist for K = 3..9 with R = 2..4 (not K = 6 at R = 3)");
+        if (!vit::reg_generic_supported(K, R)) return fail(VIT_HIP_ERR_UNSUPPORTED, "generic register-plan kernels exist for K = 3..9 with R = 1..4 (not K = 6 at an odd R)");
         for (int i = 0; i < R; ++i) G[i] = 0;
     }
     std::string err;

@@ -37,7 +37,7 @@ COMMON_SETS = [
     # all polynomials zero: the GENERIC kernels of (K, R) -- polynomials read at run time, one code object for every set (what
     # vit_hip_create falls back to when neither the library nor this cache holds kernels specialised for a set)
 ]
-COMMON_SETS += [(f"GENERIC K={K} R=1/{R} (any polynomials)", K, R, (0,) * R) for K in (3, 4, 5, 6, 7, 8, 9) for R in (2, 3, 4) if (K, R) != (6, 3)]
+COMMON_SETS += [(f"GENERIC K={K} R=1/{R} (any polynomials)", K, R, (0,) * R) for K in (3, 4, 5, 6, 7, 8, 9) for R in (1, 2, 3, 4) if not (K == 6 and R % 2)]
 
 
 def parse_list(path):
